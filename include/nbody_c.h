@@ -1,0 +1,194 @@
+/* nbody_c.h -- C-ABI of libnbody_mi355.so, the MI355X (gfx950) Barnes-Hut step engine.
+ *
+ * This is the drop-in boundary for the reference's `Simulation<float>` class
+ * (reference: include/simulation.hpp:11-47, src/cuda/simulation.cu).  Every entry
+ * point cites the reference interface it replaces.  Conventions:
+ *   - plain C types only; opaque handle; int status return (0 = NBODY_OK);
+ *     nbody_last_error(handle) gives the text of the last failure on that handle
+ *     (the reference reports no errors at all and checks no CUDA call);
+ *   - a handle is not thread-safe; distinct handles are independent (kernel
+ *     arguments instead of the reference's process-global __constant__ parameters,
+ *     src/cuda/physics_common.cu:13-14, src/cuda/barnes_hut.cu:12-14);
+ *   - all device work of a handle is issued on one HIP stream owned by the handle;
+ *     entry points that return host data synchronise that stream, nbody_update()
+ *     and nbody_step() do not synchronise at all.
+ */
+#ifndef NBODY_C_H
+#define NBODY_C_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nbody_sim nbody_t;
+
+enum {
+    NBODY_OK = 0,
+    NBODY_ERR_INVALID = 1,  /* bad argument / unsupported parameter value        */
+    NBODY_ERR_HIP = 2,      /* a HIP runtime call failed                         */
+    NBODY_ERR_STATE = 3,    /* call sequence error (e.g. update before spawn)    */
+    NBODY_ERR_DEVICE = 4,   /* a kernel reported an internal error (spin limit)  */
+    NBODY_ERR_IO = 5
+};
+
+/* nbody_params.flags */
+enum {
+    NBODY_FLAG_TIMING = 1u << 0,       /* record per-stage HIP events every step             */
+    NBODY_FLAG_NO_FUSED_VEL = 1u << 1  /* run the velocity half-kick as its own kernel        */
+};
+
+/* The first 11 fields are Simulation<T>::Params, same order and meaning
+ * (reference: include/simulation.hpp:15-28).  mem_traversal_queues is accepted and
+ * ignored: the traversal keeps its node stack in LDS and needs no global queues.
+ * traversal_group_size must be 64 (one wave64 per group) or 32. */
+typedef struct nbody_params {
+    int32_t num_points;
+    int32_t max_num_codes_per_leaf;
+    int32_t traversal_group_size;
+    uint64_t mem_traversal_queues;
+    float theta;
+    float dt;
+    float gravity;
+    float softening_factor;
+    float domain_size;
+    float velocity_dampening;
+    int32_t num_steps_validator;
+    /* extensions */
+    int32_t morton_bits; /* bits per axis: 10 (30-bit keys, u32) or 21 (63-bit keys, u64) */
+    int32_t device_id;   /* HIP device ordinal; -1 = the calling thread's current device  */
+    uint32_t flags;
+    uint64_t seed;       /* seed of the spawn_* samplers (reference: 42, simulation.cu:67) */
+} nbody_params;
+
+/* Fills *p with the reference renderer's defaults (src/renderer.cpp:297-321, disk
+ * values for dt/softening) plus morton_bits=10, traversal_group_size=64, seed=42. */
+void nbody_default_params(nbody_params *p);
+
+/* Simulation(Params&)  (reference: include/simulation.hpp:30, src/cuda/simulation.cu:131-136).
+ * Unlike the reference's headless constructor this one does install the physics
+ * parameters (the reference only does so in the GL constructor, simulation.cu:67-72). */
+int nbody_create(const nbody_params *params, nbody_t **out);
+/* ~Simulation() (include/simulation.hpp:38). */
+void nbody_destroy(nbody_t *sim);
+const char *nbody_last_error(nbody_t *sim);
+
+/* spawn_uniform / spawn_sphere / spawn_disk (include/simulation.hpp:32-34,
+ * src/cuda/simulation.cu:170-220, include/cuda/initial_conditions.cuh:20-147):
+ * same distributions and constants; counter-based RNG keyed by (seed, particle).
+ * Each one ends with the reference's exec_post_spawn(): sort + tree build, no forces. */
+int nbody_spawn_uniform(nbody_t *sim);
+int nbody_spawn_sphere(nbody_t *sim);
+int nbody_spawn_disk(nbody_t *sim);
+/* Plummer sphere, scale radius a, truncated at r_max, total mass 1, at rest (no
+ * counterpart in the reference beyond commented-out code, initial_conditions.cuh:226-243). */
+int nbody_spawn_plummer(nbody_t *sim, float a, float r_max);
+
+/* Host-side samplers only (no device work): fill caller arrays of n floats.
+ * kind: 0 uniform, 1 sphere, 2 disk, 3 plummer (p0 = a, p1 = r_max). */
+int nbody_sample_ic(int kind, int n, uint64_t seed, float domain_size, float gravity, float p0,
+                    float p1, float *x, float *y, float *z, float *vx, float *vy, float *vz,
+                    float *m);
+
+/* Load particles from host arrays (each n floats; vx/vy/vz may be NULL = 0) and run
+ * exec_post_spawn().  No reference counterpart (it has no particle input besides spawn_*). */
+int nbody_set_state(nbody_t *sim, const float *x, const float *y, const float *z,
+                    const float *vx, const float *vy, const float *vz, const float *m);
+
+/* Simulation::update()  (include/simulation.hpp:35, src/cuda/simulation.cu:224-238):
+ * kick-drift, Morton sort, tree build, traversal, kick.  nbody_step = n updates. */
+int nbody_update(nbody_t *sim);
+int nbody_step(nbody_t *sim, int n);
+/* Blocks until all queued work of this handle is done; reports device-side errors. */
+int nbody_sync(nbody_t *sim);
+
+/* Simulation::get_num_octree_nodes() (include/simulation.hpp:36). */
+int nbody_get_num_octree_nodes(nbody_t *sim, int32_t *out);
+/* Simulation::write_validation_history() (include/simulation.hpp:37,
+ * src/cuda/validator.cu:322-353): CSV `sys_energy,sys_energy_ap,avg_acc_err`. */
+int nbody_write_validation_history(nbody_t *sim, const char *csv_path);
+
+/* Current particle state in the CURRENT (Morton-sorted) order; id[i] is the index the
+ * particle had when it was spawned / set.  Any pointer may be NULL.  The reference has
+ * no getters (state lives in GL buffers, src/cuda/simulation.cu:39-51). */
+int nbody_get_state(nbody_t *sim, float *x, float *y, float *z, float *vx, float *vy,
+                    float *vz, float *m, float *ax, float *ay, float *az, uint32_t *id);
+
+/* Zero-copy device views, valid until the next update/spawn/set_state. */
+typedef struct nbody_dev_view {
+    int32_t n;
+    const float *x, *y, *z, *vx, *vy, *vz, *ax, *ay, *az, *m;
+    const float *posm; /* float4 (x,y,z,m) per particle */
+    const uint32_t *id;
+    void *stream;      /* hipStream_t of the handle */
+} nbody_dev_view;
+int nbody_get_device_ptrs(nbody_t *sim, nbody_dev_view *out);
+
+/* Sizes of the last built tree: U unique codes, M leaves, n_oct octree nodes. */
+int nbody_get_tree_counts(nbody_t *sim, int32_t *U, int32_t *M, int32_t *n_oct);
+
+/* Host copies of the build products of the last update/spawn (the integer topology
+ * contract + centre of mass).  Every pointer may be NULL (skipped); the caller sizes the
+ * arrays from num_points / nbody_get_tree_counts: codes,perm: N; unique: U; first_pt:
+ * U+1; leaf_first_code_idx: M+1; node arrays: n_oct; list_len: ceil(N/group).
+ * codes/unique are widened to u64 for both key widths. */
+typedef struct nbody_octree_view {
+    uint64_t *codes_sorted;
+    int32_t *perm;
+    uint64_t *unique;
+    int32_t *first_pt;
+    int32_t *leaf_first_code_idx;
+    int32_t *first_child;   /* -1 for leaves */
+    int32_t *num_children;
+    int32_t *leaves_begin;
+    int32_t *leaves_end;
+    int32_t *depth;
+    int32_t *level;
+    float *size;
+    int32_t *points_begin;
+    int32_t *points_end;    /* inclusive */
+    int32_t *parent;        /* -1 for the root */
+    float *comx, *comy, *comz, *mass;
+    uint32_t *list_len;     /* per group: sources interacted with in the last traversal */
+} nbody_octree_view;
+int nbody_get_octree(nbody_t *sim, nbody_octree_view *host_out);
+
+/* Per-stage device times (ms, HIP events on the handle's stream) summed over the steps
+ * run since the last call, and the number of steps summed; needs NBODY_FLAG_TIMING.
+ * interactions = sum over those steps of sum_g list_len[g] * bodies_in_group(g). */
+typedef struct nbody_timings {
+    int32_t steps;
+    float ms_integrate; /* kick-drift + Morton encode                        */
+    float ms_sort;      /* radix sort + particle permute                     */
+    float ms_build;     /* unique, leaves, radix tree, depth, rank, emit     */
+    float ms_com;       /* centre-of-mass aggregation                        */
+    float ms_traverse;  /* traversal kernel (+ fused velocity kick)          */
+    float ms_total;     /* first event to last event of each step            */
+    uint64_t interactions;
+} nbody_timings;
+int nbody_get_timings(nbody_t *sim, nbody_timings *out);
+
+/* O(N^2) direct sum (reference: compute_ap_forces, src/cuda/validator.cu:134-174) of
+ * nt target bodies against ns source bodies, both float4 (x,y,z,m) device arrays.
+ * acc = gravity * sum; if accumulate != 0 the result is added to ax/ay/az (tile-by-tile
+ * use by the ring all-gather path).  stream = hipStream_t or NULL. */
+int nbody_direct_sum_dev(const float *targets_posm, int32_t nt, const float *sources_posm,
+                         int32_t ns, float softening_factor, float gravity, float *ax,
+                         float *ay, float *az, int32_t accumulate, void *stream);
+/* Direct sum over the handle's own particles (current order); host outputs, n floats each. */
+int nbody_direct_sum(nbody_t *sim, float *ax, float *ay, float *az);
+
+/* Multi-GPU sharded traversal: restrict nbody_update()'s traversal to groups
+ * [group_begin, group_end) of the sorted order; the caller (one process per GPU) then
+ * exchanges the accelerations (nbody_dev_view.ax/ay/az slices) with an all-gather and
+ * calls nbody_finish_step() to apply the velocity kick to every particle.
+ * group_end = -1 restores the single-GPU behaviour. */
+int nbody_set_traversal_range(nbody_t *sim, int32_t group_begin, int32_t group_end);
+int nbody_finish_step(nbody_t *sim);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBODY_C_H */

@@ -1,0 +1,297 @@
+"""nbody_amd -- Python binding of libnbody_mi355.so (ctypes over the C-ABI in include/nbody_c.h).
+
+`Simulation` mirrors the reference's `Simulation<float>` class (reference:
+include/simulation.hpp:11-47): a `Params` record with the same fields, `spawn_uniform()`,
+`spawn_sphere()`, `spawn_disk()`, `update()`, `get_num_octree_nodes()`,
+`write_validation_history()`.  Everything is computed by the HIP library; there is no CPU
+fallback: importing works without a GPU, any compute call without the library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnbody_mi355.so")
+
+OK = 0
+FLAG_TIMING = 1 << 0
+FLAG_NO_FUSED_VEL = 1 << 1
+
+IC_UNIFORM, IC_SPHERE, IC_DISK, IC_PLUMMER = 0, 1, 2, 3
+
+
+class CParams(C.Structure):
+    """struct nbody_params (include/nbody_c.h); first 11 fields == Simulation<T>::Params."""
+    _fields_ = [
+        ("num_points", C.c_int32),
+        ("max_num_codes_per_leaf", C.c_int32),
+        ("traversal_group_size", C.c_int32),
+        ("mem_traversal_queues", C.c_uint64),
+        ("theta", C.c_float),
+        ("dt", C.c_float),
+        ("gravity", C.c_float),
+        ("softening_factor", C.c_float),
+        ("domain_size", C.c_float),
+        ("velocity_dampening", C.c_float),
+        ("num_steps_validator", C.c_int32),
+        ("morton_bits", C.c_int32),
+        ("device_id", C.c_int32),
+        ("flags", C.c_uint32),
+        ("seed", C.c_uint64),
+    ]
+
+
+class CDevView(C.Structure):
+    _fields_ = [("n", C.c_int32)] + [(k, C.c_void_p) for k in
+                                     ("x", "y", "z", "vx", "vy", "vz", "ax", "ay", "az", "m",
+                                      "posm", "id", "stream")]
+
+
+_OCT_FIELDS = [
+    ("codes_sorted", np.uint64), ("perm", np.int32), ("unique", np.uint64),
+    ("first_pt", np.int32), ("leaf_first_code_idx", np.int32), ("first_child", np.int32),
+    ("num_children", np.int32), ("leaves_begin", np.int32), ("leaves_end", np.int32),
+    ("depth", np.int32), ("level", np.int32), ("size", np.float32), ("points_begin", np.int32),
+    ("points_end", np.int32), ("parent", np.int32), ("comx", np.float32), ("comy", np.float32),
+    ("comz", np.float32), ("mass", np.float32), ("list_len", np.uint32),
+]
+
+
+class COctreeView(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k, _ in _OCT_FIELDS]
+
+
+class CTimings(C.Structure):
+    _fields_ = [("steps", C.c_int32), ("ms_integrate", C.c_float), ("ms_sort", C.c_float),
+                ("ms_build", C.c_float), ("ms_com", C.c_float), ("ms_traverse", C.c_float),
+                ("ms_total", C.c_float), ("interactions", C.c_uint64)]
+
+
+EXPORTS = [
+    "nbody_default_params", "nbody_create", "nbody_destroy", "nbody_last_error",
+    "nbody_spawn_uniform", "nbody_spawn_sphere", "nbody_spawn_disk", "nbody_spawn_plummer",
+    "nbody_sample_ic", "nbody_set_state", "nbody_update", "nbody_step", "nbody_sync",
+    "nbody_get_num_octree_nodes", "nbody_write_validation_history", "nbody_get_state",
+    "nbody_get_device_ptrs", "nbody_get_tree_counts", "nbody_get_octree", "nbody_get_timings",
+    "nbody_direct_sum_dev", "nbody_direct_sum", "nbody_set_traversal_range", "nbody_finish_step",
+]
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Loads libnbody_mi355.so (built in-tree by `make -C nbody_amd/csrc`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `make -C nbody_amd/csrc` "
+            "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    fp = C.POINTER(C.c_float)
+    lib.nbody_default_params.argtypes = [C.POINTER(CParams)]
+    lib.nbody_default_params.restype = None
+    lib.nbody_create.argtypes = [C.POINTER(CParams), C.POINTER(C.c_void_p)]
+    lib.nbody_destroy.argtypes = [C.c_void_p]
+    lib.nbody_destroy.restype = None
+    lib.nbody_last_error.argtypes = [C.c_void_p]
+    lib.nbody_last_error.restype = C.c_char_p
+    for name in ("nbody_spawn_uniform", "nbody_spawn_sphere", "nbody_spawn_disk", "nbody_update",
+                 "nbody_sync", "nbody_finish_step"):
+        getattr(lib, name).argtypes = [C.c_void_p]
+    lib.nbody_spawn_plummer.argtypes = [C.c_void_p, C.c_float, C.c_float]
+    lib.nbody_sample_ic.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_float, C.c_float, C.c_float,
+                                    C.c_float] + [fp] * 7
+    lib.nbody_set_state.argtypes = [C.c_void_p] + [fp] * 7
+    lib.nbody_step.argtypes = [C.c_void_p, C.c_int]
+    lib.nbody_get_num_octree_nodes.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    lib.nbody_write_validation_history.argtypes = [C.c_void_p, C.c_char_p]
+    lib.nbody_get_state.argtypes = [C.c_void_p] + [fp] * 10 + [C.POINTER(C.c_uint32)]
+    lib.nbody_get_device_ptrs.argtypes = [C.c_void_p, C.POINTER(CDevView)]
+    lib.nbody_get_tree_counts.argtypes = [C.c_void_p] + [C.POINTER(C.c_int32)] * 3
+    lib.nbody_get_octree.argtypes = [C.c_void_p, C.POINTER(COctreeView)]
+    lib.nbody_get_timings.argtypes = [C.c_void_p, C.POINTER(CTimings)]
+    lib.nbody_direct_sum_dev.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float,
+                                         C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                         C.c_void_p]
+    lib.nbody_direct_sum.argtypes = [C.c_void_p] + [fp] * 3
+    lib.nbody_set_traversal_range.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    _lib = lib
+    return lib
+
+
+def _fptr(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def sample_ic(kind: int, n: int, seed: int = 42, domain_size: float = 5.0, gravity: float = 1.0,
+              p0: float = 0.0, p1: float = 0.0):
+    """Host-side initial-condition sampler of the library: dict of float32 arrays."""
+    lib = load_library()
+    out = {k: np.empty(n, np.float32) for k in ("x", "y", "z", "vx", "vy", "vz", "m")}
+    rc = lib.nbody_sample_ic(kind, n, seed, domain_size, gravity, p0, p1,
+                             *[_fptr(out[k]) for k in ("x", "y", "z", "vx", "vy", "vz", "m")])
+    if rc != OK:
+        raise RuntimeError(f"nbody_sample_ic failed with status {rc}")
+    return out
+
+
+@dataclass
+class Params:
+    """Simulation<T>::Params (reference: include/simulation.hpp:15-28) + extensions.
+    Defaults are the reference renderer's (src/renderer.cpp:297-321, disk dt/softening)."""
+    num_points: int = 1 << 18
+    max_num_codes_per_leaf: int = 32
+    traversal_group_size: int = 64
+    mem_traversal_queues: int = (1 << 20) * 50
+    theta: float = 0.75
+    dt: float = 1e-4
+    gravity: float = 1.0
+    softening_factor: float = 0.001
+    domain_size: float = 5.0
+    velocity_dampening: float = 0.0
+    num_steps_validator: int = 0
+    morton_bits: int = 10
+    device_id: int = -1
+    flags: int = 0
+    seed: int = 42
+
+    def to_c(self) -> CParams:
+        return CParams(**{k: getattr(self, k) for k, _ in CParams._fields_})
+
+
+class Simulation:
+    """Headless drop-in for the reference's Simulation<float> (include/simulation.hpp)."""
+
+    def __init__(self, params: Params):
+        self._lib = load_library()
+        self.params = params
+        self._h = C.c_void_p()
+        cp = params.to_c()
+        rc = self._lib.nbody_create(C.byref(cp), C.byref(self._h))
+        if rc != OK:
+            self._h = C.c_void_p()
+            raise RuntimeError(f"nbody_create failed with status {rc}")
+
+    # -- lifetime -----------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.nbody_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int):
+        if rc != OK:
+            msg = self._lib.nbody_last_error(self._h)
+            raise RuntimeError(f"nbody status {rc}: {msg.decode() if msg else ''}")
+
+    # -- the reference's surface ---------------------------------------------
+    def spawn_uniform(self):
+        self._check(self._lib.nbody_spawn_uniform(self._h))
+
+    def spawn_sphere(self):
+        self._check(self._lib.nbody_spawn_sphere(self._h))
+
+    def spawn_disk(self):
+        self._check(self._lib.nbody_spawn_disk(self._h))
+
+    def spawn_plummer(self, a: float = 0.1, r_max: float = 1.0):
+        self._check(self._lib.nbody_spawn_plummer(self._h, a, r_max))
+
+    def update(self):
+        self._check(self._lib.nbody_update(self._h))
+
+    def step(self, n: int):
+        self._check(self._lib.nbody_step(self._h, n))
+
+    def get_num_octree_nodes(self) -> int:
+        out = C.c_int32()
+        self._check(self._lib.nbody_get_num_octree_nodes(self._h, C.byref(out)))
+        return out.value
+
+    def write_validation_history(self, csv_file_path: str):
+        self._check(self._lib.nbody_write_validation_history(self._h, csv_file_path.encode()))
+
+    # -- additions -----------------------------------------------------------
+    def sync(self):
+        self._check(self._lib.nbody_sync(self._h))
+
+    def set_state(self, x, y, z, m, vx=None, vy=None, vz=None):
+        n = self.params.num_points
+        arrs = []
+        for a in (x, y, z, vx, vy, vz, m):
+            if a is None:
+                arrs.append(None)
+            else:
+                a = np.ascontiguousarray(a, np.float32)
+                assert a.shape == (n,)
+                arrs.append(a)
+        self._check(self._lib.nbody_set_state(self._h, *[_fptr(a) for a in arrs]))
+
+    def get_state(self) -> dict:
+        n = self.params.num_points
+        names = ("x", "y", "z", "vx", "vy", "vz", "m", "ax", "ay", "az")
+        out = {k: np.empty(n, np.float32) for k in names}
+        out["id"] = np.empty(n, np.uint32)
+        self._check(self._lib.nbody_get_state(
+            self._h, *[_fptr(out[k]) for k in names],
+            out["id"].ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
+
+    def tree_counts(self):
+        u, m, no = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self._lib.nbody_get_tree_counts(self._h, C.byref(u), C.byref(m), C.byref(no)))
+        return u.value, m.value, no.value
+
+    def get_octree(self) -> dict:
+        """All build products of the last update/spawn as numpy arrays."""
+        n = self.params.num_points
+        U, M, no = self.tree_counts()
+        ngroups = (n + self.params.traversal_group_size - 1) // self.params.traversal_group_size
+        sizes = {"codes_sorted": n, "perm": n, "unique": U, "first_pt": U + 1,
+                 "leaf_first_code_idx": M + 1, "list_len": ngroups}
+        out, view = {}, COctreeView()
+        for k, dt in _OCT_FIELDS:
+            out[k] = np.empty(sizes.get(k, no), dt)
+            setattr(view, k, out[k].ctypes.data)
+        self._check(self._lib.nbody_get_octree(self._h, C.byref(view)))
+        out["U"], out["M"], out["n_oct"] = U, M, no
+        return out
+
+    def get_timings(self) -> dict:
+        t = CTimings()
+        self._check(self._lib.nbody_get_timings(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in CTimings._fields_}
+
+    def device_view(self) -> CDevView:
+        v = CDevView()
+        self._check(self._lib.nbody_get_device_ptrs(self._h, C.byref(v)))
+        return v
+
+    def direct_sum(self):
+        n = self.params.num_points
+        out = [np.empty(n, np.float32) for _ in range(3)]
+        self._check(self._lib.nbody_direct_sum(self._h, *[_fptr(a) for a in out]))
+        return out
+
+    def set_traversal_range(self, g0: int, g1: int):
+        self._check(self._lib.nbody_set_traversal_range(self._h, g0, g1))
+
+    def finish_step(self):
+        self._check(self._lib.nbody_finish_step(self._h))

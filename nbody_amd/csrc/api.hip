@@ -1,0 +1,676 @@
+// api.hip -- the C-ABI of libnbody_mi355.so (declared in include/nbody_c.h): handle
+// lifetime, initial conditions, step sequencing, getters, timing.
+//
+// Step sequencing follows Simulation<T>::update() and Impl::update_points/update_octree/
+// update_bodies_* (reference: src/cuda/simulation.cu:75-119,160-168,224-238); initial
+// conditions follow InitialConditions<T> (include/cuda/initial_conditions.cuh:20-147) with
+// the constants of Simulation<T>::spawn_* (src/cuda/simulation.cu:170-220).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <new>
+#include <vector>
+
+#include "nbody_internal.hpp"
+
+namespace nb {
+hipError_t launch_count_interactions(Sim *s, unsigned long long *out);
+}
+
+using namespace nb;
+
+namespace {
+
+#define NB_HIP(sim, call)                                                                    \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            (sim)->err = std::string(#call) + ": " + hipGetErrorString(e_);                  \
+            return NBODY_ERR_HIP;                                                            \
+        }                                                                                    \
+    } while (0)
+
+int fail(Sim *s, int code, const std::string &msg)
+{
+    s->err = msg;
+    return code;
+}
+
+template <typename T>
+hipError_t dalloc(T **p, size_t count)
+{
+    return hipMalloc((void **) p, std::max<size_t>(count, 1) * sizeof(T));
+}
+
+void free_all(Sim *s)
+{
+    auto F = [](void *p) { if (p) (void) hipFree(p); };
+    for (int i = 0; i < 2; ++i) {
+        F(s->x[i]); F(s->y[i]); F(s->z[i]); F(s->m[i]); F(s->vhx[i]); F(s->vhy[i]); F(s->vhz[i]);
+        F(s->vx[i]); F(s->vy[i]); F(s->vz[i]); F(s->id[i]); F(s->keys[i]); F(s->vals[i]);
+    }
+    F(s->ax); F(s->ay); F(s->az); F(s->posm); F(s->ghist); F(s->zero_block); F(s->com_counter);
+    F(s->counts); F(s->unique); F(s->first_pt); F(s->lfc); F(s->leaf_key); F(s->rt_pd);
+    F(s->rt_level); F(s->rt_lb); F(s->rt_le); F(s->rt_left); F(s->rt_right); F(s->depth_key);
+    F(s->bfs); F(s->octid); F(s->o_depth); F(s->o_first_child); F(s->o_num_children); F(s->o_lb);
+    F(s->o_le); F(s->o_level); F(s->o_pb); F(s->o_pe); F(s->o_parent); F(s->o_size); F(s->o_wsum);
+    F(s->nodeA); F(s->nodeB); F(s->list_len); F(s->inter_dev);
+    if (s->counts_host) (void) hipHostFree(s->counts_host);
+    for (int r = 0; r < TIMING_RING; ++r)
+        for (int k = 0; k < EV_COUNT; ++k)
+            if (s->ev[r][k]) (void) hipEventDestroy(s->ev[r][k]);
+    if (s->stream) (void) hipStreamDestroy(s->stream);
+}
+
+int alloc_all(Sim *s)
+{
+    const size_t n = (size_t) s->n;
+    for (int i = 0; i < 2; ++i) {
+        NB_HIP(s, dalloc(&s->x[i], n)); NB_HIP(s, dalloc(&s->y[i], n)); NB_HIP(s, dalloc(&s->z[i], n));
+        NB_HIP(s, dalloc(&s->m[i], n));
+        NB_HIP(s, dalloc(&s->vhx[i], n)); NB_HIP(s, dalloc(&s->vhy[i], n)); NB_HIP(s, dalloc(&s->vhz[i], n));
+        NB_HIP(s, dalloc(&s->vx[i], n)); NB_HIP(s, dalloc(&s->vy[i], n)); NB_HIP(s, dalloc(&s->vz[i], n));
+        NB_HIP(s, dalloc(&s->id[i], n));
+        NB_HIP(s, hipMalloc(&s->keys[i], n * s->key_bytes));
+        NB_HIP(s, dalloc(&s->vals[i], n));
+        NB_HIP(s, hipMemsetAsync(s->vhx[i], 0, n * 4, s->stream));
+        NB_HIP(s, hipMemsetAsync(s->vhy[i], 0, n * 4, s->stream));
+        NB_HIP(s, hipMemsetAsync(s->vhz[i], 0, n * 4, s->stream));
+        NB_HIP(s, hipMemsetAsync(s->vx[i], 0, n * 4, s->stream));
+        NB_HIP(s, hipMemsetAsync(s->vy[i], 0, n * 4, s->stream));
+        NB_HIP(s, hipMemsetAsync(s->vz[i], 0, n * 4, s->stream));
+    }
+    NB_HIP(s, dalloc(&s->ax, n)); NB_HIP(s, dalloc(&s->ay, n)); NB_HIP(s, dalloc(&s->az, n));
+    NB_HIP(s, dalloc(&s->posm, n));
+
+    // sort scratch: ghist[8*256] | tickets[16] | status[P][tiles][256]
+    s->sort_tiles = (int) ((n + SORT_TILE - 1) / SORT_TILE);
+    const int passes = s->key_bytes == 4 ? 4 : 8;
+    s->sort_status_bytes = (8 * 256 + 16 + (size_t) passes * s->sort_tiles * 256) * sizeof(uint32_t);
+    NB_HIP(s, hipMalloc((void **) &s->ghist, s->sort_status_bytes));
+
+    // build scratch zeroed once per build: tickets[16] | scan_status[2][T] | dhist[256] |
+    // rank_status[R][256]
+    s->max_scan_tiles = (int) ((n + SCAN_TILE - 1) / SCAN_TILE);
+    s->rank_tiles = (int) ((2 * n + SORT_TILE - 1) / SORT_TILE);
+    const size_t zwords = 16 + 2 * (size_t) s->max_scan_tiles + 256 + (size_t) s->rank_tiles * 256;
+    s->zero_bytes = (zwords * 4 + 15) / 16 * 16;
+    NB_HIP(s, hipMalloc((void **) &s->zero_block, s->zero_bytes));
+    uint32_t *zw = (uint32_t *) s->zero_block;
+    s->tickets = zw;
+    s->scan_status = zw + 16;
+    s->dhist = s->scan_status + 2 * (size_t) s->max_scan_tiles;
+    s->rank_status = s->dhist + 256;
+    NB_HIP(s, dalloc(&s->com_counter, 2 * n));
+    NB_HIP(s, hipMemsetAsync(s->com_counter, 0, 2 * n * 4, s->stream));
+
+    NB_HIP(s, dalloc(&s->counts, 1));
+    NB_HIP(s, hipMemsetAsync(s->counts, 0, sizeof(Counts), s->stream));
+    NB_HIP(s, hipHostMalloc((void **) &s->counts_host, sizeof(Counts)));
+
+    NB_HIP(s, hipMalloc(&s->unique, n * s->key_bytes));
+    NB_HIP(s, hipMalloc(&s->leaf_key, n * s->key_bytes));
+    NB_HIP(s, dalloc(&s->first_pt, n + 1)); NB_HIP(s, dalloc(&s->lfc, n + 1));
+    NB_HIP(s, dalloc(&s->rt_pd, 2 * n)); NB_HIP(s, dalloc(&s->rt_level, 2 * n));
+    NB_HIP(s, dalloc(&s->rt_lb, n)); NB_HIP(s, dalloc(&s->rt_le, n));
+    NB_HIP(s, dalloc(&s->rt_left, n)); NB_HIP(s, dalloc(&s->rt_right, n));
+    NB_HIP(s, dalloc(&s->depth_key, 2 * n)); NB_HIP(s, dalloc(&s->bfs, 2 * n));
+    NB_HIP(s, dalloc(&s->octid, 2 * n)); NB_HIP(s, dalloc(&s->o_depth, 2 * n));
+    NB_HIP(s, dalloc(&s->o_first_child, 2 * n)); NB_HIP(s, dalloc(&s->o_num_children, 2 * n));
+    NB_HIP(s, dalloc(&s->o_lb, 2 * n)); NB_HIP(s, dalloc(&s->o_le, 2 * n));
+    NB_HIP(s, dalloc(&s->o_level, 2 * n)); NB_HIP(s, dalloc(&s->o_pb, 2 * n));
+    NB_HIP(s, dalloc(&s->o_pe, 2 * n)); NB_HIP(s, dalloc(&s->o_parent, 2 * n));
+    NB_HIP(s, dalloc(&s->o_size, 2 * n)); NB_HIP(s, dalloc(&s->o_wsum, 2 * n));
+    NB_HIP(s, dalloc(&s->nodeA, 2 * n)); NB_HIP(s, dalloc(&s->nodeB, 2 * n));
+    const size_t ngroups = (n + s->group - 1) / s->group;
+    NB_HIP(s, dalloc(&s->list_len, ngroups));
+    NB_HIP(s, hipMemsetAsync(s->list_len, 0, std::max<size_t>(ngroups, 1) * 4, s->stream));
+    NB_HIP(s, dalloc(&s->inter_dev, (size_t) TIMING_RING));
+    NB_HIP(s, hipMemsetAsync(s->inter_dev, 0, TIMING_RING * 8, s->stream));
+    if (s->p.flags & NBODY_FLAG_TIMING)
+        for (int r = 0; r < TIMING_RING; ++r)
+            for (int k = 0; k < EV_COUNT; ++k) NB_HIP(s, hipEventCreate(&s->ev[r][k]));
+    return NBODY_OK;
+}
+
+// ---- counter-based RNG: every draw is a pure function of (seed, particle, draw index) ----
+inline uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+inline double u01(uint64_t seed, uint64_t i, uint64_t k)
+{
+    const uint64_t h = splitmix64(splitmix64(seed ^ (i * 0xD1342543DE82EF95ull)) + k);
+    return (double) (h >> 11) * (1.0 / 9007199254740992.0);  // [0,1)
+}
+inline double urange(uint64_t seed, uint64_t i, uint64_t k, double lo, double hi)
+{
+    return u01(seed, i, k) * (hi - lo) + lo;
+}
+// Box-Muller (include/cuda/initial_conditions.cuh:166-173); 1-u keeps log() finite.
+inline double normal(uint64_t seed, uint64_t i, uint64_t k, double mean, double sd)
+{
+    const double r = std::sqrt(-2.0 * std::log(1.0 - u01(seed, i, k)));
+    const double th = urange(seed, i, k + 1, 0.0, 2.0 * M_PI);
+    return r * std::cos(th) * sd + mean;
+}
+
+int sample_ic(int kind, int n, uint64_t seed, float domain, float gravity, float p0, float p1,
+              float *x, float *y, float *z, float *vx, float *vy, float *vz, float *m)
+{
+    const double c = domain * 0.5;
+    auto clampd = [&](double v) { return (float) std::max(0.0, std::min((double) domain, v)); };
+    for (int i = 0; i < n; ++i) {
+        double px = c, py = c, pz = c, ux = 0, uy = 0, uz = 0, mass = 1.0;
+        switch (kind) {
+        case 0:  // uniform cube of side 1 (initial_conditions.cuh:20-47, simulation.cu:170-182)
+            px = c + urange(seed, i, 0, -0.5, 0.5);
+            py = c + urange(seed, i, 1, -0.5, 0.5);
+            pz = c + urange(seed, i, 2, -0.5, 0.5);
+            break;
+        case 1: {  // uniform sphere r = 0.5 (initial_conditions.cuh:49-80, simulation.cu:185-198)
+            const double r = std::cbrt(u01(seed, i, 0)) * 0.5;
+            const double th = std::acos(urange(seed, i, 1, -1.0, 1.0));
+            const double ph = urange(seed, i, 2, 0.0, 2.0 * M_PI);
+            px = c + r * std::sin(th) * std::cos(ph);
+            py = c + r * std::sin(th) * std::sin(ph);
+            pz = c + r * std::cos(th);
+            break;
+        }
+        case 2: {  // Keplerian disk (initial_conditions.cuh:82-147, simulation.cu:200-220)
+            const double star = 10.0, disk = 1.0, rmin = 0.03, rmax = 0.30, alpha = -1.5, h = 0.05;
+            if (i == 0) { mass = star; break; }
+            const double maxp = std::pow(rmax, alpha + 1), minp = std::pow(rmin, alpha + 1);
+            const double r = std::pow(u01(seed, i, 0) * (maxp - minp) + minp, 1.0 / (alpha + 1));
+            const double th = urange(seed, i, 1, 0.0, 2.0 * M_PI);
+            px = c + r * std::cos(th);
+            py = c + r * std::sin(th);
+            pz = c + r * normal(seed, i, 2, 0.0, h);
+            const double enc = star + disk * (std::pow(r, alpha + 1) - minp) / (maxp - minp);
+            const double vk = std::sqrt(gravity * enc / r);
+            ux = vk * std::sin(th);
+            uy = -vk * std::cos(th);
+            mass = disk / n;
+            break;
+        }
+        case 3: {  // Plummer sphere, scale a = p0, truncated at p1, total mass 1, cold
+            const double a = p0, rcut = p1;
+            double r;
+            uint64_t k = 0;
+            do {
+                const double u = std::max(u01(seed, i, 8 + k), 1e-12);
+                r = a / std::sqrt(std::pow(u, -2.0 / 3.0) - 1.0);
+                ++k;
+            } while (r > rcut && k < 64);
+            if (r > rcut) r = rcut;
+            const double cz = urange(seed, i, 1, -1.0, 1.0);
+            const double ph = urange(seed, i, 2, 0.0, 2.0 * M_PI);
+            const double sxy = std::sqrt(std::max(0.0, 1.0 - cz * cz));
+            px = c + r * sxy * std::cos(ph);
+            py = c + r * sxy * std::sin(ph);
+            pz = c + r * cz;
+            mass = 1.0 / n;
+            break;
+        }
+        default: return NBODY_ERR_INVALID;
+        }
+        x[i] = clampd(px); y[i] = clampd(py); z[i] = clampd(pz);
+        if (vx) vx[i] = (float) ux;
+        if (vy) vy[i] = (float) uy;
+        if (vz) vz[i] = (float) uz;
+        m[i] = (float) mass;
+    }
+    return NBODY_OK;
+}
+
+int check_device_error(Sim *s)
+{
+    if (s->counts_host->err) {
+        char buf[96];
+        snprintf(buf, sizeof buf, "device-side error bits 0x%x (1=spin limit, 2=stack, 4=range)",
+                 s->counts_host->err);
+        return fail(s, NBODY_ERR_DEVICE, buf);
+    }
+    return NBODY_OK;
+}
+
+int fetch_counts(Sim *s)
+{
+    NB_HIP(s, hipMemcpyAsync(s->counts_host, s->counts, sizeof(Counts), hipMemcpyDeviceToHost,
+                             s->stream));
+    NB_HIP(s, hipStreamSynchronize(s->stream));
+    return check_device_error(s);
+}
+
+// update_points + update_octree (src/cuda/simulation.cu:75-102) after the keys are encoded.
+int build_after_encode(Sim *s, bool permute_all)
+{
+    NB_HIP(s, launch_sort(s));
+    NB_HIP(s, launch_permute(s, permute_all));
+    return NBODY_OK;
+}
+
+// exec_post_spawn (src/cuda/simulation.cu:160-168): sort and build, accelerations stay 0.
+int post_spawn(Sim *s)
+{
+    const size_t n = (size_t) s->n;
+    NB_HIP(s, hipMemsetAsync(s->ax, 0, n * 4, s->stream));
+    NB_HIP(s, hipMemsetAsync(s->ay, 0, n * 4, s->stream));
+    NB_HIP(s, hipMemsetAsync(s->az, 0, n * 4, s->stream));
+    NB_HIP(s, launch_morton_only(s));
+    int rc = build_after_encode(s, true);
+    if (rc) return rc;
+    NB_HIP(s, launch_build(s));
+    NB_HIP(s, launch_com(s));
+    s->spawned = true;
+    s->pending_vel = false;
+    s->ev_pending = 0;
+    s->hist_e.clear(); s->hist_e_ap.clear(); s->hist_err.clear();
+    return fetch_counts(s);
+}
+
+int upload_state(Sim *s, const float *x, const float *y, const float *z, const float *vx,
+                 const float *vy, const float *vz, const float *m)
+{
+    const size_t n = (size_t) s->n, b = n * 4;
+    const int c = s->cur;
+    std::vector<uint32_t> ids(n);
+    for (size_t i = 0; i < n; ++i) ids[i] = (uint32_t) i;
+    NB_HIP(s, hipMemcpyAsync(s->x[c], x, b, hipMemcpyHostToDevice, s->stream));
+    NB_HIP(s, hipMemcpyAsync(s->y[c], y, b, hipMemcpyHostToDevice, s->stream));
+    NB_HIP(s, hipMemcpyAsync(s->z[c], z, b, hipMemcpyHostToDevice, s->stream));
+    NB_HIP(s, hipMemcpyAsync(s->m[c], m, b, hipMemcpyHostToDevice, s->stream));
+    if (vx) NB_HIP(s, hipMemcpyAsync(s->vx[c], vx, b, hipMemcpyHostToDevice, s->stream));
+    else NB_HIP(s, hipMemsetAsync(s->vx[c], 0, b, s->stream));
+    if (vy) NB_HIP(s, hipMemcpyAsync(s->vy[c], vy, b, hipMemcpyHostToDevice, s->stream));
+    else NB_HIP(s, hipMemsetAsync(s->vy[c], 0, b, s->stream));
+    if (vz) NB_HIP(s, hipMemcpyAsync(s->vz[c], vz, b, hipMemcpyHostToDevice, s->stream));
+    else NB_HIP(s, hipMemsetAsync(s->vz[c], 0, b, s->stream));
+    NB_HIP(s, hipMemsetAsync(s->vhx[c], 0, b, s->stream));
+    NB_HIP(s, hipMemsetAsync(s->vhy[c], 0, b, s->stream));
+    NB_HIP(s, hipMemsetAsync(s->vhz[c], 0, b, s->stream));
+    NB_HIP(s, hipMemcpyAsync(s->id[c], ids.data(), b, hipMemcpyHostToDevice, s->stream));
+    NB_HIP(s, hipStreamSynchronize(s->stream));  // host staging buffers go out of scope
+    return post_spawn(s);
+}
+
+int spawn(Sim *s, int kind, float p0, float p1)
+{
+    const size_t n = (size_t) s->n;
+    std::vector<float> x(n), y(n), z(n), vx(n), vy(n), vz(n), m(n);
+    int rc = sample_ic(kind, s->n, s->p.seed, s->p.domain_size, s->p.gravity, p0, p1, x.data(),
+                       y.data(), z.data(), vx.data(), vy.data(), vz.data(), m.data());
+    if (rc) return fail(s, rc, "unknown initial condition kind");
+    return upload_state(s, x.data(), y.data(), z.data(), vx.data(), vy.data(), vz.data(),
+                        m.data());
+}
+
+struct DevGuard {
+    int prev = -1;
+    explicit DevGuard(int dev) { (void) hipGetDevice(&prev); if (prev != dev) (void) hipSetDevice(dev); }
+    ~DevGuard() { if (prev >= 0) (void) hipSetDevice(prev); }
+};
+
+}  // namespace
+
+extern "C" {
+
+void nbody_default_params(nbody_params *p)
+{
+    std::memset(p, 0, sizeof *p);
+    p->num_points = 1 << 18;
+    p->max_num_codes_per_leaf = 32;
+    p->traversal_group_size = 64;
+    p->mem_traversal_queues = (size_t) (1 << 20) * 50;
+    p->theta = 0.75f;
+    p->dt = 1e-4f;
+    p->gravity = 1.0f;
+    p->softening_factor = 0.001f;
+    p->domain_size = 5.0f;
+    p->velocity_dampening = 0.0f;
+    p->num_steps_validator = 0;
+    p->morton_bits = 10;
+    p->device_id = -1;
+    p->flags = 0;
+    p->seed = 42;
+}
+
+int nbody_create(const nbody_params *params, nbody_t **out)
+{
+    if (!params || !out) return NBODY_ERR_INVALID;
+    *out = nullptr;
+    const nbody_params &p = *params;
+    if (p.num_points < 1 || p.num_points >= (1 << 29)) return NBODY_ERR_INVALID;
+    if (p.morton_bits != 10 && p.morton_bits != 21) return NBODY_ERR_INVALID;
+    if (p.traversal_group_size != 64 && p.traversal_group_size != 32) return NBODY_ERR_INVALID;
+    if (p.max_num_codes_per_leaf < 1 || !(p.domain_size > 0.0f) || !(p.theta >= 0.0f) ||
+        !(p.softening_factor > 0.0f))
+        return NBODY_ERR_INVALID;
+    Sim *s = new (std::nothrow) Sim();
+    if (!s) return NBODY_ERR_INVALID;
+    s->p = p;
+    s->n = p.num_points;
+    s->group = p.traversal_group_size;
+    s->key_bytes = p.morton_bits == 10 ? 4 : 8;
+    int dev = p.device_id;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) { delete s; return NBODY_ERR_HIP; }
+    s->device = dev;
+    DevGuard guard(dev);
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete s;
+        return NBODY_ERR_HIP;
+    }
+    int rc = alloc_all(s);
+    if (rc == NBODY_OK && hipStreamSynchronize(s->stream) != hipSuccess) rc = NBODY_ERR_HIP;
+    if (rc != NBODY_OK) {
+        fprintf(stderr, "nbody_create: %s\n", s->err.c_str());
+        free_all(s);
+        delete s;
+        return rc;
+    }
+    *out = reinterpret_cast<nbody_t *>(s);
+    return NBODY_OK;
+}
+
+void nbody_destroy(nbody_t *h)
+{
+    if (!h) return;
+    Sim *s = reinterpret_cast<Sim *>(h);
+    DevGuard guard(s->device);
+    if (s->stream) (void) hipStreamSynchronize(s->stream);
+    free_all(s);
+    delete s;
+}
+
+const char *nbody_last_error(nbody_t *h)
+{
+    return h ? reinterpret_cast<Sim *>(h)->err.c_str() : "null handle";
+}
+
+int nbody_sample_ic(int kind, int n, uint64_t seed, float domain_size, float gravity, float p0,
+                    float p1, float *x, float *y, float *z, float *vx, float *vy, float *vz,
+                    float *m)
+{
+    if (n < 1 || !x || !y || !z || !m) return NBODY_ERR_INVALID;
+    return sample_ic(kind, n, seed, domain_size, gravity, p0, p1, x, y, z, vx, vy, vz, m);
+}
+
+#define NB_ENTER(h)                                  \
+    if (!(h)) return NBODY_ERR_INVALID;              \
+    Sim *s = reinterpret_cast<Sim *>(h);             \
+    DevGuard guard_(s->device)
+
+int nbody_spawn_uniform(nbody_t *h) { NB_ENTER(h); return spawn(s, 0, 0, 0); }
+int nbody_spawn_sphere(nbody_t *h) { NB_ENTER(h); return spawn(s, 1, 0, 0); }
+int nbody_spawn_disk(nbody_t *h) { NB_ENTER(h); return spawn(s, 2, 0, 0); }
+int nbody_spawn_plummer(nbody_t *h, float a, float r_max)
+{
+    NB_ENTER(h);
+    if (!(a > 0.0f) || !(r_max > 0.0f)) return fail(s, NBODY_ERR_INVALID, "plummer: a, r_max > 0");
+    return spawn(s, 3, a, r_max);
+}
+
+int nbody_set_state(nbody_t *h, const float *x, const float *y, const float *z, const float *vx,
+                    const float *vy, const float *vz, const float *m)
+{
+    NB_ENTER(h);
+    if (!x || !y || !z || !m) return fail(s, NBODY_ERR_INVALID, "set_state: x, y, z, m required");
+    return upload_state(s, x, y, z, vx, vy, vz, m);
+}
+
+int nbody_update(nbody_t *h)
+{
+    NB_ENTER(h);
+    if (!s->spawned) return fail(s, NBODY_ERR_STATE, "update before spawn/set_state");
+    if (s->pending_vel) return fail(s, NBODY_ERR_STATE, "nbody_finish_step not called");
+    const bool timing = (s->p.flags & NBODY_FLAG_TIMING) != 0;
+    const int slot = s->ev_head;
+    if (timing && s->ev_pending == TIMING_RING)
+        return fail(s, NBODY_ERR_STATE, "timing ring full: call nbody_get_timings");
+    auto mark = [&](int k) -> hipError_t {
+        return timing ? hipEventRecord(s->ev[slot][k], s->stream) : hipSuccess;
+    };
+    const bool sharded = s->trav_g1 >= 0;
+    const bool fuse = !sharded && !(s->p.flags & NBODY_FLAG_NO_FUSED_VEL);
+    NB_HIP(s, mark(EV_BEGIN));
+    NB_HIP(s, launch_integrate_morton(s));
+    NB_HIP(s, mark(EV_INTEGRATE));
+    int rc = build_after_encode(s, false);
+    if (rc) return rc;
+    NB_HIP(s, mark(EV_SORT));
+    NB_HIP(s, launch_build(s));
+    NB_HIP(s, mark(EV_BUILD));
+    NB_HIP(s, launch_com(s));
+    NB_HIP(s, mark(EV_COM));
+    NB_HIP(s, launch_traverse(s, fuse));
+    if (!fuse && !sharded) NB_HIP(s, launch_vel_kick(s));
+    NB_HIP(s, mark(EV_TRAVERSE));
+    if (timing) {
+        NB_HIP(s, launch_count_interactions(s, (unsigned long long *) (s->inter_dev + slot)));
+        s->ev_head = (slot + 1) % TIMING_RING;
+        s->ev_pending++;
+    }
+    if (sharded) s->pending_vel = true;
+    return NBODY_OK;
+}
+
+int nbody_finish_step(nbody_t *h)
+{
+    NB_ENTER(h);
+    if (!s->pending_vel) return fail(s, NBODY_ERR_STATE, "no sharded step pending");
+    NB_HIP(s, launch_vel_kick(s));
+    s->pending_vel = false;
+    return NBODY_OK;
+}
+
+int nbody_set_traversal_range(nbody_t *h, int32_t g0, int32_t g1)
+{
+    NB_ENTER(h);
+    const int ngroups = (s->n + s->group - 1) / s->group;
+    if (g1 >= 0 && (g0 < 0 || g0 > g1 || g1 > ngroups))
+        return fail(s, NBODY_ERR_INVALID, "traversal range outside [0, ngroups]");
+    s->trav_g0 = g0;
+    s->trav_g1 = g1;
+    return NBODY_OK;
+}
+
+int nbody_step(nbody_t *h, int n)
+{
+    for (int i = 0; i < n; ++i) {
+        int rc = nbody_update(h);
+        if (rc) return rc;
+    }
+    return NBODY_OK;
+}
+
+int nbody_sync(nbody_t *h)
+{
+    NB_ENTER(h);
+    return fetch_counts(s);
+}
+
+int nbody_get_num_octree_nodes(nbody_t *h, int32_t *out)
+{
+    NB_ENTER(h);
+    if (!out) return fail(s, NBODY_ERR_INVALID, "null output");
+    int rc = fetch_counts(s);
+    if (rc) return rc;
+    *out = s->counts_host->n_oct;
+    return NBODY_OK;
+}
+
+int nbody_get_tree_counts(nbody_t *h, int32_t *U, int32_t *M, int32_t *n_oct)
+{
+    NB_ENTER(h);
+    int rc = fetch_counts(s);
+    if (rc) return rc;
+    if (U) *U = s->counts_host->U;
+    if (M) *M = s->counts_host->M;
+    if (n_oct) *n_oct = s->counts_host->n_oct;
+    return NBODY_OK;
+}
+
+int nbody_get_state(nbody_t *h, float *x, float *y, float *z, float *vx, float *vy, float *vz,
+                    float *m, float *ax, float *ay, float *az, uint32_t *id)
+{
+    NB_ENTER(h);
+    const size_t b = (size_t) s->n * 4;
+    const int c = s->cur;
+    auto D2H = [&](void *dst, const void *src) -> hipError_t {
+        return dst ? hipMemcpyAsync(dst, src, b, hipMemcpyDeviceToHost, s->stream) : hipSuccess;
+    };
+    NB_HIP(s, D2H(x, s->x[c])); NB_HIP(s, D2H(y, s->y[c])); NB_HIP(s, D2H(z, s->z[c]));
+    NB_HIP(s, D2H(vx, s->vx[c])); NB_HIP(s, D2H(vy, s->vy[c])); NB_HIP(s, D2H(vz, s->vz[c]));
+    NB_HIP(s, D2H(m, s->m[c]));
+    NB_HIP(s, D2H(ax, s->ax)); NB_HIP(s, D2H(ay, s->ay)); NB_HIP(s, D2H(az, s->az));
+    NB_HIP(s, D2H(id, s->id[c]));
+    return fetch_counts(s);
+}
+
+int nbody_get_device_ptrs(nbody_t *h, nbody_dev_view *out)
+{
+    NB_ENTER(h);
+    if (!out) return fail(s, NBODY_ERR_INVALID, "null output");
+    const int c = s->cur;
+    out->n = s->n;
+    out->x = s->x[c]; out->y = s->y[c]; out->z = s->z[c];
+    out->vx = s->vx[c]; out->vy = s->vy[c]; out->vz = s->vz[c];
+    out->ax = s->ax; out->ay = s->ay; out->az = s->az;
+    out->m = s->m[c];
+    out->posm = reinterpret_cast<const float *>(s->posm);
+    out->id = s->id[c];
+    out->stream = (void *) s->stream;
+    return NBODY_OK;
+}
+
+int nbody_get_octree(nbody_t *h, nbody_octree_view *v)
+{
+    NB_ENTER(h);
+    if (!v) return fail(s, NBODY_ERR_INVALID, "null output");
+    int rc = fetch_counts(s);
+    if (rc) return rc;
+    const size_t n = (size_t) s->n;
+    const size_t U = (size_t) s->counts_host->U, M = (size_t) s->counts_host->M;
+    const size_t no = (size_t) s->counts_host->n_oct;
+    auto D2H = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
+        return dst ? hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) : hipSuccess;
+    };
+    auto keys64 = [&](uint64_t *dst, const void *src, size_t cnt) -> hipError_t {
+        if (!dst) return hipSuccess;
+        if (s->key_bytes == 8) return hipMemcpy(dst, src, cnt * 8, hipMemcpyDeviceToHost);
+        std::vector<uint32_t> tmp(cnt);
+        hipError_t e = hipMemcpy(tmp.data(), src, cnt * 4, hipMemcpyDeviceToHost);
+        for (size_t i = 0; i < cnt; ++i) dst[i] = tmp[i];
+        return e;
+    };
+    NB_HIP(s, keys64(v->codes_sorted, s->keys[s->sorted_buf], n));
+    NB_HIP(s, D2H(v->perm, s->vals[s->sorted_buf], n * 4));
+    NB_HIP(s, keys64(v->unique, s->unique, U));
+    NB_HIP(s, D2H(v->first_pt, s->first_pt, (U + 1) * 4));
+    NB_HIP(s, D2H(v->leaf_first_code_idx, s->lfc, (M + 1) * 4));
+    NB_HIP(s, D2H(v->first_child, s->o_first_child, no * 4));
+    NB_HIP(s, D2H(v->num_children, s->o_num_children, no * 4));
+    NB_HIP(s, D2H(v->leaves_begin, s->o_lb, no * 4));
+    NB_HIP(s, D2H(v->leaves_end, s->o_le, no * 4));
+    NB_HIP(s, D2H(v->depth, s->o_depth, no * 4));
+    NB_HIP(s, D2H(v->level, s->o_level, no * 4));
+    NB_HIP(s, D2H(v->size, s->o_size, no * 4));
+    NB_HIP(s, D2H(v->points_begin, s->o_pb, no * 4));
+    NB_HIP(s, D2H(v->points_end, s->o_pe, no * 4));
+    NB_HIP(s, D2H(v->parent, s->o_parent, no * 4));
+    if (v->comx || v->comy || v->comz || v->mass) {
+        std::vector<Float4> a(no);
+        NB_HIP(s, hipMemcpy(a.data(), s->nodeA, no * sizeof(Float4), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < no; ++i) {
+            if (v->comx) v->comx[i] = a[i].x;
+            if (v->comy) v->comy[i] = a[i].y;
+            if (v->comz) v->comz[i] = a[i].z;
+            if (v->mass) v->mass[i] = a[i].w;
+        }
+    }
+    const size_t ngroups = (n + s->group - 1) / s->group;
+    NB_HIP(s, D2H(v->list_len, s->list_len, ngroups * 4));
+    return NBODY_OK;
+}
+
+int nbody_get_timings(nbody_t *h, nbody_timings *out)
+{
+    NB_ENTER(h);
+    if (!out) return fail(s, NBODY_ERR_INVALID, "null output");
+    std::memset(out, 0, sizeof *out);
+    if (!(s->p.flags & NBODY_FLAG_TIMING)) return fail(s, NBODY_ERR_STATE, "NBODY_FLAG_TIMING not set");
+    int rc = fetch_counts(s);
+    if (rc) return rc;
+    std::vector<uint64_t> inter(TIMING_RING);
+    NB_HIP(s, hipMemcpy(inter.data(), s->inter_dev, TIMING_RING * 8, hipMemcpyDeviceToHost));
+    const int pending = s->ev_pending;
+    for (int i = 0; i < pending; ++i) {
+        const int slot = ((s->ev_head - pending + i) % TIMING_RING + TIMING_RING) % TIMING_RING;
+        float t[EV_COUNT] = {0};
+        for (int k = 1; k < EV_COUNT; ++k)
+            NB_HIP(s, hipEventElapsedTime(&t[k], s->ev[slot][k - 1], s->ev[slot][k]));
+        float tot = 0;
+        NB_HIP(s, hipEventElapsedTime(&tot, s->ev[slot][EV_BEGIN], s->ev[slot][EV_TRAVERSE]));
+        out->ms_integrate += t[EV_INTEGRATE];
+        out->ms_sort += t[EV_SORT];
+        out->ms_build += t[EV_BUILD];
+        out->ms_com += t[EV_COM];
+        out->ms_traverse += t[EV_TRAVERSE];
+        out->ms_total += tot;
+        out->interactions += inter[slot];
+    }
+    out->steps = pending;
+    s->ev_pending = 0;
+    return NBODY_OK;
+}
+
+int nbody_direct_sum_dev(const float *targets_posm, int32_t nt, const float *sources_posm,
+                         int32_t ns, float softening_factor, float gravity, float *ax, float *ay,
+                         float *az, int32_t accumulate, void *stream)
+{
+    if (!targets_posm || !sources_posm || !ax || !ay || !az || nt < 0 || ns < 0)
+        return NBODY_ERR_INVALID;
+    hipError_t e = launch_direct(reinterpret_cast<const Float4 *>(targets_posm), nt,
+                                 reinterpret_cast<const Float4 *>(sources_posm), ns,
+                                 softening_factor * softening_factor, gravity, ax, ay, az,
+                                 accumulate, (hipStream_t) stream);
+    return e == hipSuccess ? NBODY_OK : NBODY_ERR_HIP;
+}
+
+int nbody_direct_sum(nbody_t *h, float *ax, float *ay, float *az)
+{
+    NB_ENTER(h);
+    if (!s->spawned) return fail(s, NBODY_ERR_STATE, "direct sum before spawn/set_state");
+    const size_t n = (size_t) s->n;
+    float *d = nullptr;
+    NB_HIP(s, hipMalloc((void **) &d, 3 * n * 4));
+    hipError_t e = launch_direct(s->posm, s->n, s->posm, s->n,
+                                 s->p.softening_factor * s->p.softening_factor, s->p.gravity, d,
+                                 d + n, d + 2 * n, 0, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    if (e == hipSuccess && ax) e = hipMemcpy(ax, d, n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && ay) e = hipMemcpy(ay, d + n, n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && az) e = hipMemcpy(az, d + 2 * n, n * 4, hipMemcpyDeviceToHost);
+    (void) hipFree(d);
+    NB_HIP(s, e);
+    return NBODY_OK;
+}
+
+int nbody_write_validation_history(nbody_t *h, const char *csv_path)
+{
+    NB_ENTER(h);
+    if (!csv_path) return fail(s, NBODY_ERR_INVALID, "null path");
+    std::ofstream out(csv_path);
+    if (!out) return fail(s, NBODY_ERR_IO, std::string("cannot open ") + csv_path);
+    out << "sys_energy,sys_energy_ap,avg_acc_err" << std::endl;
+    for (size_t i = 0; i < s->hist_e.size(); ++i)
+        out << s->hist_e[i] << "," << s->hist_e_ap[i] << "," << s->hist_err[i] << std::endl;
+    return NBODY_OK;
+}
+
+}  // extern "C"

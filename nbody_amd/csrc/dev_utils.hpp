@@ -1,0 +1,168 @@
+// dev_utils.hpp -- wave64 / workgroup primitives shared by the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nb {
+
+constexpr int WAVE = 64;
+
+// Device-side error word (one per handle).  Kernels only ever OR bits into it.
+enum : uint32_t {
+    DEV_ERR_SPIN = 1u,       // a look-back spin hit its bound
+    DEV_ERR_STACK = 2u,      // traversal stack invariant violated
+    DEV_ERR_RANGE = 4u       // an index left its array
+};
+
+__device__ __forceinline__ int lane_id() { return (int) __lane_id(); }
+
+// Number of set bits of `mask` below the calling lane.
+__device__ __forceinline__ int mbcnt(unsigned long long mask)
+{
+    return (int) __builtin_amdgcn_mbcnt_hi((unsigned) (mask >> 32),
+                                           __builtin_amdgcn_mbcnt_lo((unsigned) mask, 0u));
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+// Inclusive prefix sum across the 64 lanes.
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
+{
+    const int l = lane_id();
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        uint32_t t = __shfl_up(v, o, WAVE);
+        if (l >= o) v += t;
+    }
+    return v;
+}
+
+// Exclusive prefix sum over a workgroup of NW waves (blockDim.x == 64*NW).
+// `scratch` is NW+1 words of LDS.  Returns the exclusive prefix; *total = workgroup sum.
+// Contains two __syncthreads(); all threads must call it.
+template <int NW>
+__device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t *scratch,
+                                                        uint32_t *total)
+{
+    const int l = lane_id();
+    const int w = (int) threadIdx.x >> 6;
+    uint32_t inc = wave_incl_scan_u32(v);
+    if (l == WAVE - 1) scratch[w] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        uint32_t s = scratch[i];
+        if (i < w) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+// ---------------------------------------------------------------------------
+// Single-pass chained scan ("decoupled look-back") over tiles of one launch.
+// A tile publishes one 32-bit word per scanned quantity:
+//   bits 31..30: 0 = not ready, 1 = tile aggregate, 2 = inclusive prefix
+//   bits 29..0 : value
+// The word is the whole hand-off (flag and payload travel in one naturally aligned
+// store), written and polled with relaxed agent-scope atomics, so no fence is needed.
+// Tile ids must be handed out in launch order by an atomic ticket so that every
+// predecessor of a running tile is itself running; each spin is bounded.
+// ---------------------------------------------------------------------------
+constexpr uint32_t LB_AGG = 1u << 30;
+constexpr uint32_t LB_PREFIX = 2u << 30;
+constexpr uint32_t LB_MASK = (1u << 30) - 1u;
+constexpr uint32_t LB_SPIN_LIMIT = 1u << 24;
+
+__device__ __forceinline__ void lb_store(uint32_t *p, uint32_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t lb_load(const uint32_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Poll one status word until its flag is set (bounded).
+__device__ __forceinline__ uint32_t lb_wait(const uint32_t *p, uint32_t *err)
+{
+    uint32_t w = lb_load(p);
+    uint32_t spins = 0;
+    while ((w >> 30) == 0u) {
+        if (++spins > LB_SPIN_LIMIT) {
+            atomicOr(err, (uint32_t) DEV_ERR_SPIN);
+            return LB_PREFIX;  // give up: value 0, chain terminates
+        }
+        __builtin_amdgcn_s_sleep(1);
+        w = lb_load(p);
+    }
+    return w;
+}
+
+// Wave-parallel look-back for ONE scanned quantity.  Must be called by all 64 lanes of
+// one wave (wave-uniform arguments).  status has one word per tile.  Returns the
+// exclusive prefix of `tile` and publishes its inclusive prefix.
+__device__ __forceinline__ uint32_t lb_exclusive_wave(uint32_t *status, int tile,
+                                                      uint32_t aggregate, uint32_t *err)
+{
+    const int l = lane_id();
+    if (tile == 0) {
+        if (l == 0) lb_store(&status[0], LB_PREFIX | aggregate);
+        return 0u;
+    }
+    if (l == 0) lb_store(&status[tile], LB_AGG | aggregate);
+    uint32_t excl = 0;
+    int base = tile - 1;
+    while (true) {
+        const int t = base - l;
+        uint32_t w = LB_PREFIX;  // virtual tiles before tile 0: prefix 0
+        if (t >= 0) w = lb_wait(&status[t], err);
+        const unsigned long long pm = __ballot((w >> 30) == 2u);
+        const int first = pm ? (int) __builtin_ctzll(pm) : WAVE;  // nearest tile with a prefix
+        const uint32_t v = (l <= first) ? (w & LB_MASK) : 0u;
+        excl += wave_sum_u32(v);
+        if (pm) break;
+        base -= WAVE;
+    }
+    if (l == 0) lb_store(&status[tile], LB_PREFIX | (excl + aggregate));
+    return excl;
+}
+
+// Serial look-back by a single thread for one quantity out of `stride` per tile
+// (used by the radix pass: thread d follows digit d).
+__device__ __forceinline__ uint32_t lb_exclusive_thread(uint32_t *status, int stride, int q,
+                                                        int tile, uint32_t aggregate,
+                                                        uint32_t *err)
+{
+    if (tile == 0) {
+        lb_store(&status[q], LB_PREFIX | aggregate);
+        return 0u;
+    }
+    lb_store(&status[(size_t) tile * stride + q], LB_AGG | aggregate);
+    uint32_t excl = 0;
+    for (int t = tile - 1; t >= 0; --t) {
+        const uint32_t w = lb_wait(&status[(size_t) t * stride + q], err);
+        excl += w & LB_MASK;
+        if ((w >> 30) == 2u) break;
+    }
+    lb_store(&status[(size_t) tile * stride + q], LB_PREFIX | (excl + aggregate));
+    return excl;
+}
+
+// Bijective block-id remap that puts consecutive logical ids on the same XCD (blocks
+// are dealt round-robin over the 8 XCDs, each with a private L2).  Speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks)
+{
+    const int q = nblocks >> 3, r = nblocks & 7;
+    const int x = bid & 7, k = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+}  // namespace nb

@@ -1,0 +1,221 @@
+// k_points.hip -- per-particle streaming kernels: kick-drift + Morton encode, particle
+// permute, velocity kick.  All are HBM-bound: one coalesced SoA pass each.
+//
+// Reference behaviour restated (not translated):
+//   leapfrog_integrate_pos / leapfrog_integrate_vel, impose_boundary_conditions
+//     (src/cuda/physics_common.cu:69-147)
+//   morton_encode, expand_bits (src/cuda/points.cu:3-38)
+//   Points::sort_by_codes gathers + BarnesHut::sort_bodies gathers
+//     (src/cuda/points.cu:86-113, src/cuda/barnes_hut.cu:577-587)
+#include "dev_utils.hpp"
+#include "nbody_internal.hpp"
+
+namespace nb {
+
+// 10-bit -> 30-bit spread (bit k -> bit 3k).
+__device__ __forceinline__ uint32_t spread3_10(uint32_t u)
+{
+    u &= 0x3ffu;
+    u = (u | (u << 16)) & 0x030000FFu;
+    u = (u | (u << 8)) & 0x0300F00Fu;
+    u = (u | (u << 4)) & 0x030C30C3u;
+    u = (u | (u << 2)) & 0x09249249u;
+    return u;
+}
+
+// 21-bit -> 63-bit spread (bit k -> bit 3k).
+__device__ __forceinline__ uint64_t spread3_21(uint64_t u)
+{
+    u &= 0x1fffffull;
+    u = (u | (u << 32)) & 0x001f00000000ffffull;
+    u = (u | (u << 16)) & 0x001f0000ff0000ffull;
+    u = (u | (u << 8)) & 0x100f00f00f00f00full;
+    u = (u | (u << 4)) & 0x10c30c30c30c30c3ull;
+    u = (u | (u << 2)) & 0x1249249249249249ull;
+    return u;
+}
+
+// q = (uint)(p / domain * (2^B - 1)): IEEE divide, then multiply, truncate.  The host
+// oracle performs the same two float operations; codes at cell boundaries depend on it.
+template <typename KeyT>
+__device__ __forceinline__ KeyT morton_code(float px, float py, float pz, float domain);
+
+template <>
+__device__ __forceinline__ uint32_t morton_code<uint32_t>(float px, float py, float pz,
+                                                          float domain)
+{
+    const float s = 1023.0f;
+    uint32_t qx = (uint32_t) (__fdiv_rn(px, domain) * s);
+    uint32_t qy = (uint32_t) (__fdiv_rn(py, domain) * s);
+    uint32_t qz = (uint32_t) (__fdiv_rn(pz, domain) * s);
+    return spread3_10(qx) * 4u + spread3_10(qy) * 2u + spread3_10(qz);
+}
+
+template <>
+__device__ __forceinline__ uint64_t morton_code<uint64_t>(float px, float py, float pz,
+                                                          float domain)
+{
+    const float s = 2097151.0f;
+    uint64_t qx = (uint64_t) (__fdiv_rn(px, domain) * s);
+    uint64_t qy = (uint64_t) (__fdiv_rn(py, domain) * s);
+    uint64_t qz = (uint64_t) (__fdiv_rn(pz, domain) * s);
+    return spread3_21(qx) * 4ull + spread3_21(qy) * 2ull + spread3_21(qz);
+}
+
+__device__ __forceinline__ void reflect(float &p, float &v, float domain)
+{
+    if (p < 0.0f || p > domain) {
+        v *= -1.0f;
+        p = fmaxf(0.0f, fminf(domain, p));
+    }
+}
+
+// v_half = v + 0.5*a*dt;  x += v_half*dt;  reflect;  code = morton(x).
+// 36 B read + 24 B + sizeof(KeyT) written per particle.
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_integrate_morton(
+    int n, float dt, float domain, float *__restrict__ x, float *__restrict__ y,
+    float *__restrict__ z, const float *__restrict__ vx, const float *__restrict__ vy,
+    const float *__restrict__ vz, const float *__restrict__ ax, const float *__restrict__ ay,
+    const float *__restrict__ az, float *__restrict__ vhx, float *__restrict__ vhy,
+    float *__restrict__ vhz, KeyT *__restrict__ codes)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float hx = fmaf(0.5f * ax[i], dt, vx[i]);
+    float hy = fmaf(0.5f * ay[i], dt, vy[i]);
+    float hz = fmaf(0.5f * az[i], dt, vz[i]);
+    float px = fmaf(hx, dt, x[i]);
+    float py = fmaf(hy, dt, y[i]);
+    float pz = fmaf(hz, dt, z[i]);
+    reflect(px, hx, domain);
+    reflect(py, hy, domain);
+    reflect(pz, hz, domain);
+    x[i] = px; y[i] = py; z[i] = pz;
+    vhx[i] = hx; vhy[i] = hy; vhz[i] = hz;
+    codes[i] = morton_code<KeyT>(px, py, pz, domain);
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_morton(int n, float domain, const float *__restrict__ x,
+                                                const float *__restrict__ y,
+                                                const float *__restrict__ z,
+                                                KeyT *__restrict__ codes)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    codes[i] = morton_code<KeyT>(x[i], y[i], z[i], domain);
+}
+
+// Gather every per-particle array through the sort permutation in one pass and emit the
+// packed (x,y,z,m) record the traversal reads.  ALL = also velocity and acceleration
+// (needed only right after a spawn; during a step both are overwritten later in the step).
+template <bool ALL>
+__global__ __launch_bounds__(256) void k_permute(
+    int n, const uint32_t *__restrict__ perm, const float *__restrict__ xi,
+    const float *__restrict__ yi, const float *__restrict__ zi, const float *__restrict__ mi,
+    const float *__restrict__ hxi, const float *__restrict__ hyi, const float *__restrict__ hzi,
+    const uint32_t *__restrict__ idi, float *__restrict__ xo, float *__restrict__ yo,
+    float *__restrict__ zo, float *__restrict__ mo, float *__restrict__ hxo,
+    float *__restrict__ hyo, float *__restrict__ hzo, uint32_t *__restrict__ ido,
+    Float4 *__restrict__ posm, const float *__restrict__ vxi, const float *__restrict__ vyi,
+    const float *__restrict__ vzi, float *__restrict__ vxo, float *__restrict__ vyo,
+    float *__restrict__ vzo)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = perm[i];
+    const float px = xi[s], py = yi[s], pz = zi[s], pm = mi[s];
+    xo[i] = px; yo[i] = py; zo[i] = pz; mo[i] = pm;
+    hxo[i] = hxi[s]; hyo[i] = hyi[s]; hzo[i] = hzi[s];
+    ido[i] = idi[s];
+    posm[i] = Float4{px, py, pz, pm};
+    if (ALL) {
+        vxo[i] = vxi[s]; vyo[i] = vyi[s]; vzo[i] = vzi[s];
+    }
+}
+
+// v = (v_half + 0.5*a*dt) * (1 - damp)
+__global__ __launch_bounds__(256) void k_vel_kick(int n, float dt, float keep,
+                                                  const float *__restrict__ vhx,
+                                                  const float *__restrict__ vhy,
+                                                  const float *__restrict__ vhz,
+                                                  const float *__restrict__ ax,
+                                                  const float *__restrict__ ay,
+                                                  const float *__restrict__ az,
+                                                  float *__restrict__ vx, float *__restrict__ vy,
+                                                  float *__restrict__ vz)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    vx[i] = fmaf(0.5f * ax[i], dt, vhx[i]) * keep;
+    vy[i] = fmaf(0.5f * ay[i], dt, vhy[i]) * keep;
+    vz[i] = fmaf(0.5f * az[i], dt, vhz[i]) * keep;
+}
+
+static inline int nblk(int n, int t) { return (n + t - 1) / t; }
+
+hipError_t launch_integrate_morton(Sim *s)
+{
+    const int c = s->cur;
+    if (s->key_bytes == 4)
+        hipLaunchKernelGGL(k_integrate_morton<uint32_t>, dim3(nblk(s->n, 256)), dim3(256), 0,
+                           s->stream, s->n, s->p.dt, s->p.domain_size, s->x[c], s->y[c], s->z[c],
+                           s->vx[c], s->vy[c], s->vz[c], s->ax, s->ay, s->az, s->vhx[c],
+                           s->vhy[c], s->vhz[c], (uint32_t *) s->keys[0]);
+    else
+        hipLaunchKernelGGL(k_integrate_morton<uint64_t>, dim3(nblk(s->n, 256)), dim3(256), 0,
+                           s->stream, s->n, s->p.dt, s->p.domain_size, s->x[c], s->y[c], s->z[c],
+                           s->vx[c], s->vy[c], s->vz[c], s->ax, s->ay, s->az, s->vhx[c],
+                           s->vhy[c], s->vhz[c], (uint64_t *) s->keys[0]);
+    return hipGetLastError();
+}
+
+hipError_t launch_morton_only(Sim *s)
+{
+    const int c = s->cur;
+    if (s->key_bytes == 4)
+        hipLaunchKernelGGL(k_morton<uint32_t>, dim3(nblk(s->n, 256)), dim3(256), 0, s->stream,
+                           s->n, s->p.domain_size, s->x[c], s->y[c], s->z[c],
+                           (uint32_t *) s->keys[0]);
+    else
+        hipLaunchKernelGGL(k_morton<uint64_t>, dim3(nblk(s->n, 256)), dim3(256), 0, s->stream,
+                           s->n, s->p.domain_size, s->x[c], s->y[c], s->z[c],
+                           (uint64_t *) s->keys[0]);
+    return hipGetLastError();
+}
+
+hipError_t launch_permute(Sim *s, bool all_fields)
+{
+    const int c = s->cur, o = c ^ 1;
+    const uint32_t *perm = s->vals[s->sorted_buf];
+    if (all_fields)
+        hipLaunchKernelGGL(k_permute<true>, dim3(nblk(s->n, 256)), dim3(256), 0, s->stream, s->n,
+                           perm, s->x[c], s->y[c], s->z[c], s->m[c], s->vhx[c], s->vhy[c],
+                           s->vhz[c], s->id[c], s->x[o], s->y[o], s->z[o], s->m[o], s->vhx[o],
+                           s->vhy[o], s->vhz[o], s->id[o], s->posm, s->vx[c], s->vy[c], s->vz[c],
+                           s->vx[o], s->vy[o], s->vz[o]);
+    else
+        hipLaunchKernelGGL(k_permute<false>, dim3(nblk(s->n, 256)), dim3(256), 0, s->stream, s->n,
+                           perm, s->x[c], s->y[c], s->z[c], s->m[c], s->vhx[c], s->vhy[c],
+                           s->vhz[c], s->id[c], s->x[o], s->y[o], s->z[o], s->m[o], s->vhx[o],
+                           s->vhy[o], s->vhz[o], s->id[o], s->posm, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, nullptr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // Every pair flips.  When velocity was not gathered its new buffer holds stale values;
+    // the velocity kick that ends the step overwrites all of them.
+    s->cur = o;
+    return hipSuccess;
+}
+
+hipError_t launch_vel_kick(Sim *s)
+{
+    const int c = s->cur;
+    hipLaunchKernelGGL(k_vel_kick, dim3(nblk(s->n, 256)), dim3(256), 0, s->stream, s->n, s->p.dt,
+                       1.0f - s->p.velocity_dampening, s->vhx[c], s->vhy[c], s->vhz[c], s->ax,
+                       s->ay, s->az, s->vx[c], s->vy[c], s->vz[c]);
+    return hipGetLastError();
+}
+
+}  // namespace nb

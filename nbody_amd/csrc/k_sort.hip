@@ -1,0 +1,194 @@
+// k_sort.hip -- LDS-staged onesweep LSD radix sort of (Morton key, particle index) pairs.
+//
+// Replaces the reference's cub::DeviceMergeSort::SortPairs + thrust::sequence
+// (src/cuda/points.cu:73-84).  Ascending by key, STABLE (ties keep index order), which is
+// the tie order this build pins; the reference's merge sort leaves it unspecified.
+//
+// Structure (8-bit digits, P = ceil(key_bits/8) passes):
+//   k_sort_hist : one read of the keys, all P digit histograms at once (LDS atomics, then
+//                 one global atomic per non-empty bin per workgroup).
+//   k_sort_pass : one launch per digit.  A workgroup takes a tile by atomic ticket, ranks
+//                 its keys with wave64 ballot matching, publishes the tile's 256 digit
+//                 counts and resolves their global offsets by chained look-back over the
+//                 earlier tiles (dev_utils.hpp), reorders the tile in LDS by digit and
+//                 writes each digit run to its final place with consecutive lanes on
+//                 consecutive addresses.  Keys and indices are read once and written
+//                 once per pass: 2*(sizeof(KeyT)+4) bytes per element per pass.
+#include "dev_utils.hpp"
+#include "nbody_internal.hpp"
+
+namespace nb {
+
+template <typename KeyT, int NPASS>
+__global__ __launch_bounds__(256) void k_sort_hist(const KeyT *__restrict__ keys, int n,
+                                                   uint32_t *__restrict__ ghist)
+{
+    __shared__ uint32_t h[NPASS * 256];
+    for (int j = threadIdx.x; j < NPASS * 256; j += 256) h[j] = 0;
+    __syncthreads();
+    const int stride = gridDim.x * 256;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const KeyT k = keys[i];
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p)
+            atomicAdd(&h[p * 256 + (int) ((k >> (8 * p)) & 255)], 1u);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < NPASS * 256; j += 256) {
+        const uint32_t c = h[j];
+        if (c) atomicAdd(&ghist[j], c);
+    }
+}
+
+// One digit pass.  n is read from n_dev when it is non-null (device-side element count,
+// used by the octree node ranking), else n_host.  IOTA: the value of element i is i.
+// inv_out (nullable): inv_out[value] = final position.
+template <typename KeyT, int ITEMS, bool IOTA>
+__global__ __launch_bounds__(256) void k_sort_pass(
+    const KeyT *__restrict__ kin, const uint32_t *__restrict__ vin, KeyT *__restrict__ kout,
+    uint32_t *__restrict__ vout, uint32_t *__restrict__ inv_out, const int32_t *n_dev,
+    int n_host, int shift, const uint32_t *__restrict__ ghist, uint32_t *status,
+    uint32_t *ticket, uint32_t *err)
+{
+    constexpr int NW = 4;
+    constexpr int TILE = 256 * ITEMS;
+    __shared__ uint32_t s_whist[NW][256];
+    __shared__ uint32_t s_dstart[256];
+    __shared__ uint32_t s_goff[256];
+    __shared__ uint32_t s_scan[NW + 1];
+    __shared__ uint32_t s_tile;
+    __shared__ KeyT s_keys[TILE];
+    __shared__ uint32_t s_vals[TILE];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int n = n_dev ? *n_dev : n_host;
+    const int ntiles = (n + TILE - 1) / TILE;
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    for (int j = tid; j < NW * 256; j += 256) (&s_whist[0][0])[j] = 0;
+    __syncthreads();
+    const int tile = (int) s_tile;
+    if (tile >= ntiles) return;
+    const int tile_base = tile * TILE;
+    const int tile_count = min(TILE, n - tile_base);
+
+    KeyT key[ITEMS];
+    uint32_t val[ITEMS];
+    uint32_t rank[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const int li = w * 64 * ITEMS + k * 64 + lane;
+        const bool valid = li < tile_count;
+        key[k] = valid ? kin[tile_base + li] : ~(KeyT) 0;
+        val[k] = IOTA ? (uint32_t) (tile_base + li) : (valid ? vin[tile_base + li] : 0u);
+    }
+    // Rank every key among the keys of its wave with the same digit (stable: earlier
+    // rounds first, lower lanes first).
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const int li = w * 64 * ITEMS + k * 64 + lane;
+        const bool valid = li < tile_count;
+        const uint32_t d = (uint32_t) (key[k] >> shift) & 255u;
+        unsigned long long m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bb = __ballot(bit);
+            m &= bit ? bb : ~bb;
+        }
+        const uint32_t r = (uint32_t) mbcnt(m);
+        const uint32_t c = (uint32_t) __popcll(m);
+        const uint32_t prev = s_whist[w][d];
+        __builtin_amdgcn_wave_barrier();
+        if (valid && r == 0) s_whist[w][d] = prev + c;
+        __builtin_amdgcn_wave_barrier();
+        rank[k] = prev + r;
+    }
+    __syncthreads();
+    // Thread d owns digit d: per-wave counts -> exclusive prefix over the waves.
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int ww = 0; ww < NW; ++ww) {
+        const uint32_t c = s_whist[ww][tid];
+        s_whist[ww][tid] = cnt;
+        cnt += c;
+    }
+    uint32_t tot;
+    const uint32_t dstart = block_excl_scan_u32<NW>(cnt, s_scan, &tot);
+    const uint32_t gbase = block_excl_scan_u32<NW>(ghist[tid], s_scan, &tot);
+    const uint32_t excl = lb_exclusive_thread(status, 256, tid, tile, cnt, err);
+    s_dstart[tid] = dstart;
+    s_goff[tid] = gbase + excl - dstart;  // final position = s_goff[d] + position in tile
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const int li = w * 64 * ITEMS + k * 64 + lane;
+        if (li < tile_count) {
+            const uint32_t d = (uint32_t) (key[k] >> shift) & 255u;
+            const uint32_t lp = s_dstart[d] + s_whist[w][d] + rank[k];
+            s_keys[lp] = key[k];
+            s_vals[lp] = val[k];
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < tile_count; j += 256) {
+        const KeyT kk = s_keys[j];
+        const uint32_t d = (uint32_t) (kk >> shift) & 255u;
+        const uint32_t gpos = s_goff[d] + (uint32_t) j;
+        const uint32_t v = s_vals[j];
+        kout[gpos] = kk;
+        vout[gpos] = v;
+        if (inv_out) inv_out[v] = gpos;
+    }
+}
+
+// Explicit instantiation used by the octree node ranking pass (k_tree.hip).
+void launch_rank_pass(const uint32_t *keys, uint32_t *keys_out, uint32_t *vals_out,
+                      uint32_t *inv_out, const int32_t *n_dev, int n_max, const uint32_t *hist,
+                      uint32_t *status, uint32_t *ticket, uint32_t *err, hipStream_t st)
+{
+    const int grid = (n_max + SORT_TILE - 1) / SORT_TILE;
+    hipLaunchKernelGGL((k_sort_pass<uint32_t, SORT_ITEMS, true>), dim3(grid), dim3(256), 0, st,
+                       keys, (const uint32_t *) nullptr, keys_out, vals_out, inv_out, n_dev, 0, 0,
+                       hist, status, ticket, err);
+}
+
+template <typename KeyT, int NPASS>
+static hipError_t sort_impl(Sim *s)
+{
+    const int n = s->n;
+    const int tiles = s->sort_tiles;
+    hipError_t e = hipMemsetAsync(s->ghist, 0, s->sort_status_bytes, s->stream);
+    if (e != hipSuccess) return e;
+    // layout of the zeroed block: ghist[8*256] | tickets[8] (+pad to 16) | status[P][tiles][256]
+    uint32_t *tickets = s->ghist + 8 * 256;
+    uint32_t *status = tickets + 16;
+    const int hgrid = std::min(tiles, 1024);
+    hipLaunchKernelGGL((k_sort_hist<KeyT, NPASS>), dim3(hgrid), dim3(256), 0, s->stream,
+                       (const KeyT *) s->keys[0], n, s->ghist);
+    int in = 0;
+    for (int p = 0; p < NPASS; ++p) {
+        const KeyT *kin = (const KeyT *) s->keys[in];
+        KeyT *kout = (KeyT *) s->keys[in ^ 1];
+        uint32_t *st = status + (size_t) p * tiles * 256;
+        if (p == 0)
+            hipLaunchKernelGGL((k_sort_pass<KeyT, SORT_ITEMS, true>), dim3(tiles), dim3(256), 0,
+                               s->stream, kin, (const uint32_t *) nullptr, kout, s->vals[in ^ 1],
+                               (uint32_t *) nullptr, (const int32_t *) nullptr, n, 8 * p,
+                               s->ghist + p * 256, st, tickets + p, &s->counts->err);
+        else
+            hipLaunchKernelGGL((k_sort_pass<KeyT, SORT_ITEMS, false>), dim3(tiles), dim3(256), 0,
+                               s->stream, kin, (const uint32_t *) s->vals[in], kout,
+                               s->vals[in ^ 1], (uint32_t *) nullptr, (const int32_t *) nullptr, n,
+                               8 * p, s->ghist + p * 256, st, tickets + p, &s->counts->err);
+        in ^= 1;
+    }
+    s->sorted_buf = in;  // NPASS is even: back in buffer 0
+    return hipGetLastError();
+}
+
+hipError_t launch_sort(Sim *s)
+{
+    return s->key_bytes == 4 ? sort_impl<uint32_t, 4>(s) : sort_impl<uint64_t, 8>(s);
+}
+
+}  // namespace nb

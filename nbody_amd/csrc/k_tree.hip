@@ -1,0 +1,480 @@
+// k_tree.hip -- unique codes, leaf coarsening, Karras radix tree, compressed-octree depth,
+// breadth-first node numbering, octree emission and centre-of-mass aggregation.
+//
+// The OUTPUT contract is the reference's (integer arrays bit-for-bit); the way there is
+// not.  Reference stages restated:
+//   Points::compute_unique_codes / compute_codes_first_point_idx  src/cuda/points.cu:116-142
+//   reduce_leaf_depth, merge_leaves, Btree::generate_leaves       src/cuda/btree.cu:124-187,420-455
+//   build_radix_tree, set_node_child, find_split                  src/cuda/btree.cu:37-58,90-122,190-304
+//   compute_nodes_depth x ~25 launches                            src/cuda/btree.cu:306-336,479-494
+//   sort_to_bfs_order, correct_child_pointers, compute_octree_map src/cuda/btree.cu:339-359,497-572
+//   build_octree, compute_octree_nodes_points_range               src/cuda/octree.cu:13-107
+//   leaf / per-depth / normalise COM kernels                      src/cuda/octree.cu:109-217,292-346
+// No count ever travels to the host during a build: kernels read U, M, n_bt, n_oct from
+// device memory and run grid-stride or ticketed tiles under host-known upper bounds.
+#include "dev_utils.hpp"
+#include "nbody_internal.hpp"
+
+namespace nb {
+
+void launch_rank_pass(const uint32_t *keys, uint32_t *keys_out, uint32_t *vals_out,
+                      uint32_t *inv_out, const int32_t *n_dev, int n_max, const uint32_t *hist,
+                      uint32_t *status, uint32_t *ticket, uint32_t *err, hipStream_t st);
+
+template <typename KeyT> struct KeyBits;
+template <> struct KeyBits<uint32_t> { static constexpr int KB = 30; };
+template <> struct KeyBits<uint64_t> { static constexpr int KB = 63; };
+
+// Length of the common prefix of two keys, counted from the key's top bit (bit KB-1);
+// KB for equal keys.  Same value as the reference's `__clzll(a ^ b) - 1` at KB = 63.
+__device__ __forceinline__ int lcp_keys(uint32_t a, uint32_t b)
+{
+    const uint32_t x = a ^ b;
+    return x ? __clz((int) x) - 2 : 30;
+}
+__device__ __forceinline__ int lcp_keys(uint64_t a, uint64_t b)
+{
+    const uint64_t x = a ^ b;
+    return x ? __clzll((long long) x) - 1 : 63;
+}
+
+// ---------------------------------------------------------------------------
+// Unique codes: head flags -> tile scan with look-back -> compaction.
+// unique[u], first_pt[u] (index of the first particle carrying the code), first_pt[U] = n.
+// ---------------------------------------------------------------------------
+template <typename KeyT>
+__global__ __launch_bounds__(SCAN_THREADS) void k_unique(const KeyT *__restrict__ sorted, int n,
+                                                         KeyT *__restrict__ unique,
+                                                         int32_t *__restrict__ first_pt,
+                                                         Counts *counts, uint32_t *status,
+                                                         uint32_t *ticket)
+{
+    constexpr int NW = SCAN_THREADS / 64;
+    __shared__ uint32_t s_scan[NW + 1];
+    __shared__ uint32_t s_bcast[2];
+    const int tid = threadIdx.x;
+    if (tid == 0) s_bcast[0] = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const int tile = (int) s_bcast[0];
+    const int ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (tile >= ntiles) return;
+    const int base = tile * SCAN_TILE + tid * SCAN_ITEMS;
+
+    KeyT k[SCAN_ITEMS];
+    bool f[SCAN_ITEMS];
+    KeyT prev = 0;
+    if (base > 0 && base <= n) prev = sorted[base - 1];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        const int gi = base + j;
+        k[j] = gi < n ? sorted[gi] : 0;
+        f[j] = gi < n && (gi == 0 || k[j] != prev);
+        prev = k[j];
+        cnt += f[j];
+    }
+    uint32_t tot;
+    const uint32_t excl = block_excl_scan_u32<NW>(cnt, s_scan, &tot);
+    if (tid < 64) {
+        const uint32_t te = lb_exclusive_wave(status, tile, tot, &counts->err);
+        if (tid == 0) s_bcast[1] = te;
+    }
+    __syncthreads();
+    const uint32_t tile_excl = s_bcast[1];
+    uint32_t pos = tile_excl + excl;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        if (f[j]) {
+            unique[pos] = k[j];
+            first_pt[pos] = base + j;
+            ++pos;
+        }
+    }
+    if (tile == ntiles - 1 && tid == 0) {
+        const int U = (int) (tile_excl + tot);
+        counts->U = U;
+        first_pt[U] = n;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Leaf coarsening + compaction.  A leaf is the largest octree cell around a code that
+// holds at most max_codes unique codes (never larger than the cell in which the code is
+// alone with respect to its neighbours); a code is kept iff it is the first code of its
+// leaf.  Equivalent to the reference's climb (merge_leaves) but each level is resolved by
+// two bounded binary searches on key prefixes: counts above max_codes+1 are never needed.
+// Outputs lfc[0..M) (index of each leaf's first code), lfc[M] = U (the sentinel the
+// reference gets from cub::DevicePartition's reversed rear), leaf_key[0..M), M, n_bt.
+// ---------------------------------------------------------------------------
+template <typename KeyT>
+__device__ __forceinline__ bool leaf_head_flag(const KeyT *__restrict__ u, int i, int U,
+                                               int max_codes)
+{
+    constexpr int KB = KeyBits<KeyT>::KB;
+    const KeyT c = u[i];
+    const int l1 = i > 0 ? lcp_keys(c, u[i - 1]) : -3;
+    const int l2 = i < U - 1 ? lcp_keys(c, u[i + 1]) : -3;
+    const int ld = max(l1 / 3, l2 / 3) + 1;  // C division: -3/3 = -1
+    const int lcap = min(i, max_codes + 1);
+    const int rcap = min(U - 1 - i, max_codes + 1);
+    int left_acc = 0;
+    for (int t = ld - 1; t >= 0; --t) {
+        const int sh = KB - 3 * t;
+        const KeyT pre = c >> sh;
+        int lo = 0, hi = lcap;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if ((u[i - mid] >> sh) == pre) lo = mid; else hi = mid - 1;
+        }
+        const int left = lo;
+        lo = 0; hi = rcap;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if ((u[i + mid] >> sh) == pre) lo = mid; else hi = mid - 1;
+        }
+        if (left + lo + 1 > max_codes) break;
+        left_acc = left;
+    }
+    return left_acc == 0;
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(SCAN_THREADS) void k_leaves(const KeyT *__restrict__ unique,
+                                                         int max_codes, int32_t *__restrict__ lfc,
+                                                         KeyT *__restrict__ leaf_key,
+                                                         Counts *counts, uint32_t *status,
+                                                         uint32_t *ticket)
+{
+    constexpr int NW = SCAN_THREADS / 64;
+    __shared__ uint32_t s_scan[NW + 1];
+    __shared__ uint32_t s_bcast[2];
+    const int tid = threadIdx.x;
+    const int U = counts->U;
+    if (tid == 0) s_bcast[0] = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const int tile = (int) s_bcast[0];
+    const int ntiles = (U + SCAN_TILE - 1) / SCAN_TILE;
+    if (tile >= ntiles) return;
+    const int base = tile * SCAN_TILE + tid * SCAN_ITEMS;
+    const bool single = U <= max_codes;  // whole set fits one leaf (undefined in the reference)
+
+    bool f[SCAN_ITEMS];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        const int i = base + j;
+        f[j] = false;
+        if (i < U) f[j] = single ? (i == 0) : leaf_head_flag<KeyT>(unique, i, U, max_codes);
+        cnt += f[j];
+    }
+    uint32_t tot;
+    const uint32_t excl = block_excl_scan_u32<NW>(cnt, s_scan, &tot);
+    if (tid < 64) {
+        const uint32_t te = lb_exclusive_wave(status, tile, tot, &counts->err);
+        if (tid == 0) s_bcast[1] = te;
+    }
+    __syncthreads();
+    const uint32_t tile_excl = s_bcast[1];
+    uint32_t pos = tile_excl + excl;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        if (f[j]) {
+            lfc[pos] = base + j;
+            leaf_key[pos] = unique[base + j];
+            ++pos;
+        }
+    }
+    if (tile == ntiles - 1 && tid == 0) {
+        const int M = (int) (tile_excl + tot);
+        counts->M = M;
+        counts->n_bt = 2 * M - 1;
+        lfc[M] = U;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Karras radix tree over the M leaf keys.  Node ids: leaf j -> 2j, internal i -> 2i+1,
+// root = 1.  An internal node writes its own range/level/children and, for each child,
+// rt_pd[child] = parent*2 + edge_delta, where edge_delta = 1 iff the child starts a new
+// octree level below its radix parent (always 1 for leaves).
+// ---------------------------------------------------------------------------
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_radix(const KeyT *__restrict__ lk, const Counts *counts,
+                                               int32_t *__restrict__ rt_pd,
+                                               int32_t *__restrict__ rt_level,
+                                               int32_t *__restrict__ rt_lb,
+                                               int32_t *__restrict__ rt_le,
+                                               int32_t *__restrict__ rt_left,
+                                               int32_t *__restrict__ rt_right)
+{
+    constexpr int KB = KeyBits<KeyT>::KB;
+    const int M = counts->M;
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (M == 1) {
+        if (gtid == 0) { rt_pd[0] = 1; rt_level[0] = 0; }
+        return;
+    }
+    for (int i = gtid; i < M - 1; i += gridDim.x * blockDim.x) {
+        const KeyT ki = lk[i];
+        auto lcp_at = [&](int j) -> int {
+            return (j < 0 || j > M - 1) ? -3 : lcp_keys(ki, lk[j]);
+        };
+        const int d = lcp_at(i + 1) > lcp_at(i - 1) ? 1 : -1;
+        const int lcp_min = lcp_at(i - d);
+        int l_max = 2;
+        while (lcp_at(i + l_max * d) > lcp_min) l_max <<= 1;
+        int length = 0;
+        for (int step = l_max >> 1; step >= 1; step >>= 1)
+            if (lcp_at(i + (length + step) * d) > lcp_min) length += step;
+        const int last = i + length * d;
+        const int node_lcp = lcp_keys(ki, lk[last]);
+        // split: largest s with lcp(i, i + s*d) > node_lcp
+        int s = 0, t = length;
+        do {
+            t = (t + 1) >> 1;
+            if (lcp_at(i + (s + t) * d) > node_lcp) s += t;
+        } while (t > 1);
+        const int gamma = i + s * d + min(d, 0);
+        const int lo = min(i, last), hi = max(i, last);
+        const int self = 2 * i + 1;
+        const int node_level = node_lcp / 3;
+
+        const bool l_leaf = gamma == lo;
+        const int l_id = 2 * gamma + (l_leaf ? 0 : 1);
+        const int l_lcp = l_leaf ? KB : lcp_keys(lk[gamma], lk[lo]);
+        const int l_delta = min(1, l_lcp / 3 - node_level + (l_leaf ? 1 : 0));
+        const bool r_leaf = gamma + 1 == hi;
+        const int r_id = 2 * (gamma + 1) + (r_leaf ? 0 : 1);
+        const int r_lcp = r_leaf ? KB : lcp_keys(lk[gamma + 1], lk[hi]);
+        const int r_delta = min(1, r_lcp / 3 - node_level + (r_leaf ? 1 : 0));
+
+        rt_pd[l_id] = self * 2 + l_delta;
+        rt_pd[r_id] = self * 2 + r_delta;
+        if (l_leaf) rt_level[l_id] = node_level + 1;
+        if (r_leaf) rt_level[r_id] = node_level + 1;
+        rt_level[self] = node_level;
+        rt_lb[i] = lo;
+        rt_le[i] = hi;
+        rt_left[i] = l_id;
+        rt_right[i] = r_id;
+        if (i == 0) rt_pd[1] = 1;  // root: no parent, counts as an octree node
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Compressed-octree depth of every radix node that is an octree node (edge_delta = 1):
+// number of edge_delta = 1 edges on its path to the root; one upward walk per node in a
+// single launch.  Nodes with edge_delta = 0 get key 255 and sort behind everything.
+// Also histograms the keys for the ranking pass.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_depth(const Counts *counts,
+                                               const int32_t *__restrict__ rt_pd,
+                                               uint32_t *__restrict__ depth_key,
+                                               uint32_t *__restrict__ dhist)
+{
+    __shared__ uint32_t h[MAX_DEPTH_BINS];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int n_bt = counts->n_bt;
+    const int root = n_bt == 1 ? 0 : 1;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < n_bt; r += gridDim.x * 256) {
+        const int pd = rt_pd[r];
+        uint32_t key = 255u;
+        if (pd & 1) {
+            int dsum = 0;
+            int cur = r;
+            int guard = 0;
+            while (cur != root && guard < 256) {
+                const int p = rt_pd[cur];
+                dsum += p & 1;
+                cur = p >> 1;
+                ++guard;
+            }
+            key = (uint32_t) min(dsum, 254);
+        }
+        depth_key[r] = key;
+        atomicAdd(&h[key], 1u);
+    }
+    __syncthreads();
+    const uint32_t c = h[threadIdx.x];
+    if (c) atomicAdd(&dhist[threadIdx.x], c);
+}
+
+// ---------------------------------------------------------------------------
+// Octree emission.  Octree id o = breadth-first rank (depth-major, Morton-minor) of radix
+// node bfs[o]; children of a node are contiguous.  first_child/num_children come from the
+// left-most / right-most chains through edge_delta = 0 nodes.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_emit(
+    Counts *counts, float domain, const uint32_t *__restrict__ dhist,
+    const uint32_t *__restrict__ bfs, const uint32_t *__restrict__ octid,
+    const int32_t *__restrict__ rt_pd, const int32_t *__restrict__ rt_level,
+    const int32_t *__restrict__ rt_lb, const int32_t *__restrict__ rt_le,
+    const int32_t *__restrict__ rt_left, const int32_t *__restrict__ rt_right,
+    const int32_t *__restrict__ lfc, const int32_t *__restrict__ first_pt,
+    int32_t *__restrict__ o_first_child, int32_t *__restrict__ o_num_children,
+    int32_t *__restrict__ o_lb, int32_t *__restrict__ o_le, int32_t *__restrict__ o_level,
+    float *__restrict__ o_size, int32_t *__restrict__ o_pb, int32_t *__restrict__ o_pe,
+    int32_t *__restrict__ o_parent, NodeB *__restrict__ nodeB)
+{
+    const int n_bt = counts->n_bt;
+    const int n_oct = n_bt - (int) dhist[255];
+    const int root = n_bt == 1 ? 0 : 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) counts->n_oct = n_oct;
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < n_oct; o += gridDim.x * 256) {
+        const int r = (int) bfs[o];
+        const bool leaf = (r & 1) == 0;
+        const int idx = r >> 1;
+        const int level = rt_level[r];
+        int lb, le, fc = -1, nc = 0;
+        if (leaf) {
+            lb = le = idx;
+        } else {
+            lb = rt_lb[idx];
+            le = rt_le[idx];
+            int f = rt_left[idx];
+            while (!(rt_pd[f] & 1)) f = rt_left[f >> 1];
+            int l = rt_right[idx];
+            while (!(rt_pd[l] & 1)) l = rt_right[l >> 1];
+            fc = (int) octid[f];
+            nc = (int) octid[l] - fc + 1;
+        }
+        int parent = -1;
+        if (r != root) {
+            int p = rt_pd[r] >> 1;
+            while (!(rt_pd[p] & 1)) p = rt_pd[p] >> 1;
+            parent = (int) octid[p];
+        }
+        const int pb = first_pt[lfc[lb]];
+        const int pe = first_pt[lfc[le + 1]] - 1;
+        const float size = domain / (float) (1 << level);
+        o_first_child[o] = fc;
+        o_num_children[o] = nc;
+        o_lb[o] = lb;
+        o_le[o] = le;
+        o_level[o] = level;
+        o_size[o] = size;
+        o_pb[o] = pb;
+        o_pe[o] = pe;
+        o_parent[o] = parent;
+        nodeB[o] = leaf ? NodeB{size, pb, pe - pb + 1, 1} : NodeB{size, fc, nc, 0};
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Centre of mass, one launch.  A thread sums its leaf's particles (in index order), then
+// climbs: it bumps its parent's arrival counter and stops unless it was the last child to
+// arrive, in which case it sums the parent's children (in index order) and continues.
+// Summation order is therefore fixed whatever the arrival order, and the host oracle
+// reproduces it bit for bit.
+// Cross-workgroup hand-off of the children's sums: every sum is stored write-through
+// (agent-scope atomic stores), the storing wave drains its stores (s_waitcnt vmcnt(0))
+// before the agent-scope counter add, and the last arriver reads the sums with
+// agent-scope atomic loads that bypass its L1 -- only after its add has returned.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void st_wt(float *p, float v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_wt(const float *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void k_com(const Counts *counts,
+                                             const int32_t *__restrict__ o_num_children,
+                                             const int32_t *__restrict__ o_first_child,
+                                             const int32_t *__restrict__ o_pb,
+                                             const int32_t *__restrict__ o_pe,
+                                             const int32_t *__restrict__ o_parent,
+                                             const Float4 *__restrict__ posm, Float4 *wsum,
+                                             Float4 *__restrict__ nodeA, uint32_t *counter)
+{
+    const int n_oct = counts->n_oct;
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < n_oct; o += gridDim.x * 256) {
+        if (o_num_children[o] != 0) continue;
+        float sx = 0.f, sy = 0.f, sz = 0.f, sm = 0.f;
+        const int pb = o_pb[o], pe = o_pe[o];
+        for (int p = pb; p <= pe; ++p) {
+            const Float4 q = posm[p];
+            sx = fmaf(q.w, q.x, sx);
+            sy = fmaf(q.w, q.y, sy);
+            sz = fmaf(q.w, q.z, sz);
+            sm += q.w;
+        }
+        int cur = o;
+        int guard = 0;
+        while (true) {
+            float *ws = reinterpret_cast<float *>(&wsum[cur]);
+            st_wt(ws + 0, sx); st_wt(ws + 1, sy); st_wt(ws + 2, sz); st_wt(ws + 3, sm);
+            nodeA[cur] = Float4{sx / sm, sy / sm, sz / sm, sm};
+            const int parent = o_parent[cur];
+            if (parent < 0 || ++guard > 64) break;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint32_t arrived = __hip_atomic_fetch_add(&counter[parent], 1u, __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT);
+            const int nc = o_num_children[parent];
+            if ((int) arrived != nc - 1) break;
+            const int fc = o_first_child[parent];
+            sx = sy = sz = sm = 0.f;
+            for (int c = fc; c < fc + nc; ++c) {
+                const float *cs = reinterpret_cast<const float *>(&wsum[c]);
+                sx += ld_wt(cs + 0);
+                sy += ld_wt(cs + 1);
+                sz += ld_wt(cs + 2);
+                sm += ld_wt(cs + 3);
+            }
+            cur = parent;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+template <typename KeyT>
+static hipError_t build_impl(Sim *s)
+{
+    const int n = s->n;
+    hipStream_t st = s->stream;
+    hipError_t e = hipMemsetAsync(s->zero_block, 0, s->zero_bytes, st);
+    if (e != hipSuccess) return e;
+    const int scan_grid = (n + SCAN_TILE - 1) / SCAN_TILE;
+    const KeyT *sorted = (const KeyT *) s->keys[s->sorted_buf];
+    hipLaunchKernelGGL(k_unique<KeyT>, dim3(scan_grid), dim3(SCAN_THREADS), 0, st, sorted, n,
+                       (KeyT *) s->unique, s->first_pt, s->counts, s->scan_status,
+                       s->tickets + 0);
+    hipLaunchKernelGGL(k_leaves<KeyT>, dim3(scan_grid), dim3(SCAN_THREADS), 0, st,
+                       (const KeyT *) s->unique, s->p.max_num_codes_per_leaf, s->lfc,
+                       (KeyT *) s->leaf_key, s->counts, s->scan_status + s->max_scan_tiles,
+                       s->tickets + 1);
+    const int node_grid = std::min((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_radix<KeyT>, dim3(node_grid), dim3(256), 0, st,
+                       (const KeyT *) s->leaf_key, s->counts, s->rt_pd, s->rt_level, s->rt_lb,
+                       s->rt_le, s->rt_left, s->rt_right);
+    const int depth_grid = std::min((2 * n + 255) / 256, 512);
+    hipLaunchKernelGGL(k_depth, dim3(depth_grid), dim3(256), 0, st, s->counts, s->rt_pd,
+                       s->depth_key, s->dhist);
+    launch_rank_pass(s->depth_key, s->o_depth, s->bfs, s->octid, &s->counts->n_bt, 2 * n,
+                     s->dhist, s->rank_status, s->tickets + 2, &s->counts->err, st);
+    hipLaunchKernelGGL(k_emit, dim3(node_grid), dim3(256), 0, st, s->counts, s->p.domain_size,
+                       s->dhist, s->bfs, s->octid, s->rt_pd, s->rt_level, s->rt_lb, s->rt_le,
+                       s->rt_left, s->rt_right, s->lfc, s->first_pt, s->o_first_child,
+                       s->o_num_children, s->o_lb, s->o_le, s->o_level, s->o_size, s->o_pb,
+                       s->o_pe, s->o_parent, s->nodeB);
+    return hipGetLastError();
+}
+
+hipError_t launch_build(Sim *s)
+{
+    return s->key_bytes == 4 ? build_impl<uint32_t>(s) : build_impl<uint64_t>(s);
+}
+
+hipError_t launch_com(Sim *s)
+{
+    const int grid = std::min((2 * s->n + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_com, dim3(grid), dim3(256), 0, s->stream, s->counts, s->o_num_children,
+                       s->o_first_child, s->o_pb, s->o_pe, s->o_parent, s->posm, s->o_wsum,
+                       s->nodeA, s->com_counter);
+    return hipGetLastError();
+}
+
+}  // namespace nb

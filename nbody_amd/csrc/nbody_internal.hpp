@@ -1,0 +1,126 @@
+// nbody_internal.hpp -- handle layout and stage launchers of libnbody_mi355.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/nbody_c.h"
+
+namespace nb {
+
+// Work distribution constants shared by host sizing code and kernels.
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_ITEMS = 8;                       // keys per thread per radix tile
+constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 4;                       // elements per thread in compaction tiles
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+constexpr int TRAV_WAVES = 4;                       // groups (waves) per traversal workgroup
+constexpr int TRAV_STACK = 1024;                    // LDS node stack entries per wave
+constexpr int MAX_DEPTH_BINS = 256;                 // depth key space of the node ranking pass
+constexpr int TIMING_RING = 64;
+enum { EV_BEGIN = 0, EV_INTEGRATE, EV_SORT, EV_BUILD, EV_COM, EV_TRAVERSE, EV_COUNT };
+
+struct Float4 { float x, y, z, w; };
+struct NodeB { float size; int32_t first; int32_t count; int32_t leaf; };
+
+// Device-resident counters written by the build kernels (one int each).
+struct Counts {
+    int32_t U;       // unique codes
+    int32_t M;       // leaves after coarsening
+    int32_t n_bt;    // radix-tree nodes = 2M-1
+    int32_t n_oct;   // octree nodes
+    uint32_t err;    // DEV_ERR_* bits
+    int32_t pad[3];
+};
+
+struct Sim {
+    nbody_params p{};
+    int n = 0;            // particles
+    int group = 64;
+    int key_bytes = 4;    // 4 (B=10) or 8 (B=21)
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool spawned = false;
+    std::string err;
+
+    // particle state, SoA, double buffered for the permute
+    float *x[2]{}, *y[2]{}, *z[2]{}, *m[2]{};
+    float *vhx[2]{}, *vhy[2]{}, *vhz[2]{};
+    float *vx[2]{}, *vy[2]{}, *vz[2]{};
+    uint32_t *id[2]{};
+    float *ax = nullptr, *ay = nullptr, *az = nullptr;
+    Float4 *posm = nullptr;       // (x,y,z,m) in sorted order, read by the traversal
+    int cur = 0;                  // which buffer of each pair is current
+
+    // sort
+    void *keys[2]{};              // KeyT[n] ping-pong
+    uint32_t *vals[2]{};          // index ping-pong; after the sort vals[sorted_buf] = perm
+    int sorted_buf = 0;
+    uint32_t *ghist = nullptr;    // [8][256] digit histograms
+    uint32_t *sort_status = nullptr;  // [passes][tiles][256] look-back words + tickets
+    size_t sort_status_bytes = 0;
+    int sort_tiles = 0;
+
+    // scratch zeroed once per build (tickets, look-back words, counters, histograms)
+    uint8_t *zero_block = nullptr;
+    size_t zero_bytes = 0;
+    uint32_t *tickets = nullptr;      // [8]
+    uint32_t *scan_status = nullptr;  // [3][max_scan_tiles]
+    uint32_t *dhist = nullptr;        // [256] depth histogram
+    uint32_t *rank_status = nullptr;  // [rank_tiles][256]
+    uint32_t *com_counter = nullptr;  // [2n] children-arrived counters
+    int max_scan_tiles = 0, rank_tiles = 0;
+
+    Counts *counts = nullptr;     // device
+    Counts *counts_host = nullptr;  // pinned
+
+    // build products
+    void *unique = nullptr;       // KeyT[n]
+    int32_t *first_pt = nullptr;  // [n+1]
+    int32_t *lfc = nullptr;       // [n+1] leaf_first_code_idx
+    void *leaf_key = nullptr;     // KeyT[n] first code of each leaf
+    // radix tree (transient), r = radix node id (leaf j -> 2j, internal i -> 2i+1)
+    int32_t *rt_pd = nullptr;     // [2n] parent*2 + edge_delta
+    int32_t *rt_level = nullptr;  // [2n] lcp/3 (leaves: parent level + 1)
+    int32_t *rt_lb = nullptr, *rt_le = nullptr, *rt_left = nullptr, *rt_right = nullptr;  // [n]
+    uint32_t *depth_key = nullptr;   // [2n] depth or 255 for edge_delta == 0
+    uint32_t *bfs = nullptr;         // [2n] octree id -> radix node
+    uint32_t *octid = nullptr;       // [2n] radix node -> octree id
+    // octree (capacity 2n)
+    uint32_t *o_depth = nullptr;
+    int32_t *o_first_child = nullptr, *o_num_children = nullptr, *o_lb = nullptr, *o_le = nullptr;
+    int32_t *o_level = nullptr, *o_pb = nullptr, *o_pe = nullptr, *o_parent = nullptr;
+    float *o_size = nullptr;
+    Float4 *o_wsum = nullptr;     // unnormalised (sum m*x, sum m*y, sum m*z, sum m)
+    Float4 *nodeA = nullptr;      // (comx, comy, comz, mass)
+    NodeB *nodeB = nullptr;
+    uint32_t *list_len = nullptr; // [ceil(n/group)]
+
+    // sharded traversal
+    int trav_g0 = 0, trav_g1 = -1;
+    bool pending_vel = false;
+
+    // timing
+    hipEvent_t ev[TIMING_RING][EV_COUNT]{};
+    int ev_head = 0, ev_pending = 0;
+    uint64_t *inter_dev = nullptr;   // [TIMING_RING] interactions per step
+    // validator history
+    std::vector<double> hist_e, hist_e_ap, hist_err;
+};
+
+// ---- stage launchers (each enqueues on s->stream and returns a hipError_t) ----
+hipError_t launch_integrate_morton(Sim *s);                 // kick-drift + encode -> keys[0]
+hipError_t launch_morton_only(Sim *s);                      // encode current positions
+hipError_t launch_sort(Sim *s);                             // keys/vals -> sorted keys, perm
+hipError_t launch_permute(Sim *s, bool all_fields);         // gather by perm, write posm
+hipError_t launch_build(Sim *s);                            // unique .. octree emit
+hipError_t launch_com(Sim *s);
+hipError_t launch_traverse(Sim *s, bool fuse_vel);
+hipError_t launch_vel_kick(Sim *s);
+hipError_t launch_direct(const Float4 *targets, int nt, const Float4 *sources, int ns, float eps2,
+                         float gravity, float *ax, float *ay, float *az, int accumulate,
+                         hipStream_t st);
+
+}  // namespace nb

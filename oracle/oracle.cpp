@@ -1,0 +1,782 @@
+// oracle.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// Host (CPU) restatement of the Barnes-Hut step of lechebs/nbody, used only as
+// the checker for the HIP library (tests/, __graft_entry__.smoke(), and the
+// cpu_baseline leg of bench.py).  The product library never links, loads or
+// calls anything in this file.
+//
+// PARITY UNPINNED BY REFERENCE FIXTURES: the reference ships no tests, golden
+// vectors or known-answer files for this path and its CUDA sources cannot be
+// built in this environment, so this restatement is pinned only by (a) a
+// line-by-line reading of the cited sources, (b) hand-checkable cases in
+// tests/test_oracle.py and (c) the published accuracy/energy curves.
+//
+// Every function cites the reference file:line it follows (paths relative to
+// the reference checkout).  Deliberate, documented deviations:
+//   * bits per axis B is a parameter (10 -> 30-bit keys, 21 -> the reference's
+//     63-bit keys); lcp(i,j) = clz64(ci^cj) - (64-3B), which is the reference's
+//     `__clzll(x) - 1` at B=21 (src/cuda/btree.cu:17-21).
+//   * the sort is STABLE (ties by original index); the reference's
+//     cub::DeviceMergeSort::SortPairs (src/cuda/points.cu:79-84) leaves tie
+//     order unspecified.
+//   * U <= max_num_codes_per_leaf (reference: non-terminating loop in
+//     src/cuda/btree.cu:72-76) is defined as a single root leaf.
+//   * floating point contractions are written out with fmaf() so that the GPU
+//     and this file execute the same IEEE operations.
+//   * centre-of-mass summation order is fixed (sequential over a leaf's points,
+//     sequential over an internal node's children) so it can be reproduced
+//     bit-for-bit.
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+using key_t_ = uint64_t;
+
+inline int clz64(uint64_t v) { return v ? __builtin_clzll(v) : 64; }
+
+struct Keys {
+    const key_t_ *c;
+    int n;
+    int kb;  // key bits = 3 * bits-per-axis
+};
+
+// src/cuda/btree.cu:17-21 (lcp_safe): `__clzll(a ^ b) - 1` for 63-bit keys.
+inline int lcp_safe(const Keys &k, int i, int j)
+{
+    return clz64(k.c[i] ^ k.c[j]) - (64 - k.kb);
+}
+
+// src/cuda/btree.cu:23-30 (lcp): out-of-range neighbour -> -3.
+inline int lcp(const Keys &k, int i, int j)
+{
+    if (j < 0 || j > k.n - 1) return -3;
+    return lcp_safe(k, i, j);
+}
+
+inline int sign(int x) { return (x > 0) - (x < 0); }
+
+// src/cuda/points.cu:3-12 (expand_bits), written as the definition it
+// implements: bit k of u goes to bit 3k.
+inline key_t_ spread3(key_t_ u, int bits)
+{
+    key_t_ r = 0;
+    for (int k = 0; k < bits; ++k) r |= ((u >> k) & 1ull) << (3 * k);
+    return r;
+}
+
+// src/cuda/btree.cu:60-88 (search_lr).
+int search_lr(const Keys &k, const int *leaf_depth, int dir, int idx, int depth_delta)
+{
+    int l = 0;
+    int l_max = 2;
+    int target_depth = leaf_depth[idx] - depth_delta;
+    while (lcp(k, idx, idx + dir * l_max) / 3 >= target_depth) l_max <<= 1;
+    while (l_max > 0) {
+        l_max >>= 1;
+        if (lcp(k, idx, idx + dir * (l + l_max)) / 3 >= target_depth) l += l_max;
+    }
+    return l;
+}
+
+// src/cuda/btree.cu:37-58 (find_split).
+int find_split(const Keys &k, int first, int last, int node_lcp, int dir)
+{
+    int step = 0;
+    int length = (last - first) * dir;
+    do {
+        length = (length + 1) >> 1;
+        if (lcp(k, first, first + (step + length) * dir) > node_lcp) step += length;
+    } while (length > 1);
+    return first + step * dir + std::min(dir, 0);
+}
+
+struct Btree {
+    std::vector<int> left, right, parent, lcp, edge_delta, depth, lb, le;
+    void resize(int n)
+    {
+        left.assign(n, 0); right.assign(n, 0); parent.assign(n, 0); lcp.assign(n, 0);
+        edge_delta.assign(n, 0); depth.assign(n, 0); lb.assign(n, 0); le.assign(n, 0);
+    }
+};
+
+// src/cuda/btree.cu:90-122 (set_node_child).
+void set_node_child(const Keys &k, Btree &t, std::vector<int> &child, int parent_idx,
+                    int child_idx, int first_idx, int parent_lcp)
+{
+    bool is_leaf = child_idx == first_idx;
+    int node = 2 * child_idx + !is_leaf;
+    child[2 * parent_idx + 1] = node;
+    int l = lcp_safe(k, child_idx, first_idx);
+    int delta = std::min(1, l / 3 - parent_lcp / 3 + (int) is_leaf);
+    t.parent[node] = 2 * parent_idx + 1;
+    t.edge_delta[node] = delta;
+    t.depth[node] = delta;
+    if (is_leaf) {
+        t.lcp[node] = parent_lcp + 3;
+        t.left[node] = 0;
+        t.right[node] = 0;
+        t.lb[node] = child_idx;
+        t.le[node] = child_idx;
+    }
+}
+
+// Pairwise softened force, float32.
+// include/cuda/physics_common.cuh:46-75 (accumulate_pairwise_force); the
+// reference's __frsqrt_rn is restated as 1/sqrt in float.
+inline void pair_force(float p1x, float p1y, float p1z, float p2x, float p2y, float p2z,
+                       float m2, float &fx, float &fy, float &fz, float eps2)
+{
+    float dx = p2x - p1x, dy = p2y - p1y, dz = p2z - p1z;
+    float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    float s = d2 + eps2;
+    float inv = 1.0f / sqrtf(s * s * s);
+    inv *= m2;
+    fx = fmaf(dx, inv, fx);
+    fy = fmaf(dy, inv, fy);
+    fz = fmaf(dz, inv, fz);
+}
+
+// include/cuda/physics_common.cuh:36-44 (compute_dist_sq).
+inline float dist_sq(float ax, float ay, float az, float bx, float by, float bz)
+{
+    float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+}
+
+template <typename T>
+static void permute(std::vector<T> &v, const std::vector<int32_t> &perm, std::vector<T> &tmp)
+{
+    const int n = (int) perm.size();
+    tmp.resize(n);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) tmp[i] = v[perm[i]];
+    v.swap(tmp);
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------------------
+// Morton encode.  src/cuda/points.cu:16-38: q = (u64)(p / domain * (2^B-1))
+// evaluated in float32 (divide, then multiply, truncate); x is the most
+// significant bit of each triple: code = X*4 + Y*2 + Z.
+// ---------------------------------------------------------------------------
+void orc_morton(const float *x, const float *y, const float *z, int n, float domain, int bits,
+                uint64_t *codes)
+{
+    const float scale = (float) ((1u << bits) - 1u);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        volatile float fx = x[i] / domain;
+        volatile float fy = y[i] / domain;
+        volatile float fz = z[i] / domain;
+        key_t_ qx = (key_t_) (fx * scale);
+        key_t_ qy = (key_t_) (fy * scale);
+        key_t_ qz = (key_t_) (fz * scale);
+        codes[i] = spread3(qx, bits) * 4 + spread3(qy, bits) * 2 + spread3(qz, bits);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Sort.  src/cuda/points.cu:73-84: (code, iota) pairs sorted ascending by code;
+// ties pinned to original index order (stable).  perm[i] = pre-sort index of
+// the i-th sorted body.
+// ---------------------------------------------------------------------------
+void orc_sort(const uint64_t *codes, int n, uint64_t *sorted, int32_t *perm)
+{
+    std::vector<int32_t> idx(n);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(),
+                     [&](int32_t a, int32_t b) { return codes[a] < codes[b]; });
+    for (int i = 0; i < n; ++i) {
+        perm[i] = idx[i];
+        sorted[i] = codes[idx[i]];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Unique codes + first point index.  src/cuda/points.cu:116-142 (run-length
+// encode + exclusive scan of the run lengths); first_pt[U] = n.
+// Returns U.  unique has room for n entries, first_pt for n+1.
+// ---------------------------------------------------------------------------
+int orc_unique(const uint64_t *sorted, int n, uint64_t *unique, int32_t *first_pt)
+{
+    int u = 0;
+    for (int i = 0; i < n; ++i) {
+        if (i == 0 || sorted[i] != sorted[i - 1]) {
+            unique[u] = sorted[i];
+            first_pt[u] = i;
+            ++u;
+        }
+    }
+    first_pt[u] = n;
+    return u;
+}
+
+// ---------------------------------------------------------------------------
+// Leaf coarsening.  src/cuda/btree.cu:124-187 (reduce_leaf_depth, merge_leaves)
+// and :420-455 (generate_leaves: flagged partition; the rejected tail leaves
+// leaf_first_code_idx[M] == U, which compute_octree_nodes_points_range relies
+// on, src/cuda/octree.cu:103).  Returns M; lfc has room for U+1 entries.
+// ---------------------------------------------------------------------------
+int orc_coarsen(const uint64_t *unique, int U, int bits, int max_codes, int32_t *lfc)
+{
+    Keys k{unique, U, 3 * bits};
+    if (U <= max_codes) {  // reference: undefined (search_lr never terminates)
+        lfc[0] = 0;
+        lfc[1] = U;
+        return 1;
+    }
+    std::vector<int> leaf_depth(U);
+    for (int i = 0; i < U; ++i)
+        leaf_depth[i] = std::max(lcp(k, i, i - 1) / 3, lcp(k, i, i + 1) / 3) + 1;
+
+    std::vector<char> flag(U);
+#pragma omp parallel for schedule(static)
+    for (int idx = 0; idx < U; ++idx) {
+        int left_old = 0, left = 0, right = 0, dd = 0;
+        int num = 1;  // leaf_first_in is iota (src/cuda/btree.cu:440): counts are codes
+        while (num <= max_codes) {
+            dd++;
+            left_old = left;
+            left = search_lr(k, leaf_depth.data(), -1, idx, dd);
+            right = search_lr(k, leaf_depth.data(), 1, idx, dd);
+            num = (idx + right + 1) - (idx - left);
+        }
+        flag[idx] = left_old == 0;
+    }
+    int m = 0;
+    for (int i = 0; i < U; ++i)
+        if (flag[i]) lfc[m++] = i;
+    lfc[m] = U;
+    return m;
+}
+
+// ---------------------------------------------------------------------------
+// Radix tree -> BFS order -> octree arrays.
+//   src/cuda/btree.cu:190-304 (build_radix_tree), :306-336,:479-494 (depth by
+//   pointer jumping), :497-559 (stable sort by depth, gathers, child pointer
+//   fix-up), :561-572 (octree map = exclusive scan of edge_delta);
+//   src/cuda/octree.cu:13-83 (build_octree), :85-107 (points ranges).
+// All output arrays have room for 2M-1 entries.  first_child of a leaf is
+// written as -1 (the reference leaves it stale).  Returns n_oct.
+// ---------------------------------------------------------------------------
+int orc_build_octree(const uint64_t *unique, int U, const int32_t *lfc, int M,
+                     const int32_t *first_pt, int bits, float domain, int32_t *first_child,
+                     int32_t *num_children, int32_t *leaves_begin, int32_t *leaves_end,
+                     int32_t *depth, int32_t *level, float *size, int32_t *points_begin,
+                     int32_t *points_end)
+{
+    (void) U;
+    if (M == 1) {  // single root leaf (our definition, see header)
+        first_child[0] = -1; num_children[0] = 0; leaves_begin[0] = 0; leaves_end[0] = 0;
+        depth[0] = 0; level[0] = 0; size[0] = domain;
+        points_begin[0] = first_pt[lfc[0]];
+        points_end[0] = first_pt[lfc[1]] - 1;
+        return 1;
+    }
+    // src/cuda/btree.cu:464-468: first code of each leaf.
+    std::vector<key_t_> lk(M);
+    for (int j = 0; j < M; ++j) lk[j] = unique[lfc[j]];
+    Keys k{lk.data(), M, 3 * bits};
+
+    const int nbt = 2 * M - 1;
+    Btree t;
+    t.resize(nbt);
+
+    // src/cuda/btree.cu:230-235: root.
+    t.parent[1] = 0; t.depth[1] = 0; t.edge_delta[1] = 1;
+    for (int idx = 0; idx < M - 1; ++idx) {
+        int d = sign(lcp(k, idx, idx + 1) - lcp(k, idx, idx - 1));
+        int lcp_min = lcp(k, idx, idx - d);
+        int max_length = 2;
+        while (lcp(k, idx, idx + max_length * d) > lcp_min) max_length <<= 1;
+        int length = 0;
+        int step = max_length;
+        do {
+            step >>= 1;
+            if (lcp(k, idx, idx + (length + step) * d) > lcp_min) length += step;
+        } while (step > 1);
+        int last = idx + length * d;
+        int node_lcp = lcp_safe(k, idx, last);
+        t.lcp[2 * idx + 1] = node_lcp;
+        int split = find_split(k, idx, last, node_lcp, d);
+        int min_leaf = std::min(idx, last), max_leaf = std::max(idx, last);
+        t.lb[2 * idx + 1] = min_leaf;
+        t.le[2 * idx + 1] = max_leaf;
+        set_node_child(k, t, t.left, idx, split, min_leaf, node_lcp);
+        set_node_child(k, t, t.right, idx, split + 1, max_leaf, node_lcp);
+    }
+
+    // src/cuda/btree.cu:306-336 x (ceil(log2(nbt))+3) rounds: pointer jumping.
+    {
+        int rounds = 3;
+        for (int n = 1; n < nbt; n <<= 1) rounds++;
+        std::vector<int> p_in = t.parent, d_in = t.depth, p_out(nbt), d_out(nbt);
+        for (int r = 0; r < rounds; ++r) {
+            for (int i = 0; i < nbt; ++i) {
+                int cp = p_in[i], cd = d_in[i];
+                bool flag = cp && cd > 0;
+                d_out[i] = cd + d_in[cp] * (int) flag;
+                p_out[i] = flag ? p_in[cp] : cp;
+            }
+            p_in.swap(p_out);
+            d_in.swap(d_out);
+        }
+        t.depth = d_in;
+    }
+
+    // src/cuda/btree.cu:497-559: stable sort by depth, permute, fix children.
+    std::vector<int> order(nbt), inv(nbt);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int a, int b) { return t.depth[a] < t.depth[b]; });
+    for (int i = 0; i < nbt; ++i) inv[order[i]] = i;
+    Btree s;
+    s.resize(nbt);
+    for (int i = 0; i < nbt; ++i) {
+        int o = order[i];
+        s.depth[i] = t.depth[o];
+        s.lcp[i] = t.lcp[o];
+        s.edge_delta[i] = t.edge_delta[o];
+        s.lb[i] = t.lb[o];
+        s.le[i] = t.le[o];
+        int l = t.left[o], r = t.right[o];
+        if (l != 0 || r != 0) { l = inv[l]; r = inv[r]; }
+        s.left[i] = l;
+        s.right[i] = r;
+    }
+    // src/cuda/btree.cu:561-572: octree map.
+    std::vector<int> map(nbt);
+    int acc = 0;
+    for (int i = 0; i < nbt; ++i) { map[i] = acc; acc += s.edge_delta[i]; }
+    const int n_oct = map[nbt - 1] + s.edge_delta[nbt - 1];
+
+    // src/cuda/octree.cu:26-83 (build_octree) + :13-24 (traverse).
+    for (int idx = 0; idx < nbt; ++idx) {
+        if (!s.edge_delta[idx]) continue;
+        int o = map[idx];
+        num_children[o] = 0;
+        first_child[o] = -1;
+        int lvl = s.lcp[idx] / 3;
+        level[o] = lvl;
+        size[o] = domain / (float) (1 << lvl);
+        leaves_begin[o] = s.lb[idx];
+        leaves_end[o] = s.le[idx];
+        depth[o] = s.depth[idx];
+        if (s.lb[idx] == s.le[idx]) continue;
+        int fb = idx;
+        do { fb = s.left[fb]; } while (!s.edge_delta[fb]);
+        int lbn = idx;
+        do { lbn = s.right[lbn]; } while (!s.edge_delta[lbn]);
+        first_child[o] = map[fb];
+        num_children[o] = map[lbn] - map[fb] + 1;
+    }
+    // src/cuda/octree.cu:85-107.
+    for (int o = 0; o < n_oct; ++o) {
+        points_begin[o] = first_pt[lfc[leaves_begin[o]]];
+        points_end[o] = first_pt[lfc[leaves_end[o] + 1]] - 1;
+    }
+    return n_oct;
+}
+
+// ---------------------------------------------------------------------------
+// Centre of mass.  src/cuda/octree.cu:109-217,292-346: leaves sum m*pos over
+// their points, internal nodes sum their children deepest level first, then
+// every node divides by its mass.  Order fixed as stated in the file header.
+// Nodes are in depth-major order, so a reverse index sweep is "deepest first".
+// ---------------------------------------------------------------------------
+void orc_com(int n_oct, const int32_t *first_child, const int32_t *num_children,
+             const int32_t *points_begin, const int32_t *points_end, const float *x,
+             const float *y, const float *z, const float *m, float *comx, float *comy,
+             float *comz, float *mass)
+{
+    std::vector<float> wx(n_oct), wy(n_oct), wz(n_oct);
+    for (int o = n_oct - 1; o >= 0; --o) {
+        float sx = 0.f, sy = 0.f, sz = 0.f, sm = 0.f;
+        if (num_children[o] == 0) {
+            for (int p = points_begin[o]; p <= points_end[o]; ++p) {
+                float mp = m[p];
+                sx = fmaf(mp, x[p], sx);
+                sy = fmaf(mp, y[p], sy);
+                sz = fmaf(mp, z[p], sz);
+                sm += mp;
+            }
+        } else {
+            for (int c = first_child[o]; c < first_child[o] + num_children[o]; ++c) {
+                sx += wx[c]; sy += wy[c]; sz += wz[c]; sm += mass[c];
+            }
+        }
+        wx[o] = sx; wy[o] = sy; wz[o] = sz; mass[o] = sm;
+    }
+    for (int o = 0; o < n_oct; ++o) {
+        comx[o] = wx[o] / mass[o];
+        comy[o] = wy[o] / mass[o];
+        comz[o] = wz[o] / mass[o];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Group traversal.  src/cuda/barnes_hut.cu:199-537: one group = G consecutive
+// sorted bodies; per candidate node d2min = min over the group's bodies of
+// |x_b - com|^2 (:37-61, initial value 3*domain^2); a node with no children is
+// always evaluated directly against every point of its range, self included
+// (:144-197,:428-474); otherwise size^2/d2min < theta^2 -> approximate by
+// (com, mass) (:31-35,:95-142), else open (:63-93,:404-426).  acc = G_grav * f
+// (:533-536).  The interaction SET is order independent; this walk is depth
+// first.  list_len[g] = number of (com|point) sources the group interacted
+// with; interactions = sum_g list_len[g] * bodies_in_group(g).
+// ---------------------------------------------------------------------------
+void orc_traverse(int n, int group, const float *x, const float *y, const float *z,
+                  const float *m, int n_oct, const int32_t *first_child,
+                  const int32_t *num_children, const int32_t *points_begin,
+                  const int32_t *points_end, const float *size, const float *comx,
+                  const float *comy, const float *comz, const float *mass, float theta,
+                  float eps2, float gravity, float domain, float *ax, float *ay, float *az,
+                  uint32_t *list_len)
+{
+    (void) n_oct;
+    const int ngroups = (n + group - 1) / group;
+#pragma omp parallel
+    {
+        std::vector<int> stack;
+        std::vector<float> fx(group), fy(group), fz(group);
+#pragma omp for schedule(dynamic, 16)
+        for (int g = 0; g < ngroups; ++g) {
+            const int b0 = g * group, b1 = std::min(n, b0 + group);
+            std::fill(fx.begin(), fx.end(), 0.f);
+            std::fill(fy.begin(), fy.end(), 0.f);
+            std::fill(fz.begin(), fz.end(), 0.f);
+            uint32_t cnt = 0;
+            stack.clear();
+            stack.push_back(0);
+            while (!stack.empty()) {
+                int node = stack.back();
+                stack.pop_back();
+                const int nc = num_children[node];
+                if (nc == 0) {
+                    for (int p = points_begin[node]; p <= points_end[node]; ++p) {
+                        for (int b = b0; b < b1; ++b)
+                            pair_force(x[b], y[b], z[b], x[p], y[p], z[p], m[p], fx[b - b0],
+                                       fy[b - b0], fz[b - b0], eps2);
+                        ++cnt;
+                    }
+                    continue;
+                }
+                float dmin = domain * domain * 3.0f;
+                for (int b = b0; b < b1; ++b) {
+                    float d = dist_sq(x[b], y[b], z[b], comx[node], comy[node], comz[node]);
+                    if (d <= dmin) dmin = d;
+                }
+                const float sz = size[node];
+                if (sz * sz / dmin < theta * theta) {
+                    for (int b = b0; b < b1; ++b)
+                        pair_force(x[b], y[b], z[b], comx[node], comy[node], comz[node],
+                                   mass[node], fx[b - b0], fy[b - b0], fz[b - b0], eps2);
+                    ++cnt;
+                } else {
+                    for (int c = first_child[node] + nc - 1; c >= first_child[node]; --c)
+                        stack.push_back(c);
+                }
+            }
+            for (int b = b0; b < b1; ++b) {
+                ax[b] = gravity * fx[b - b0];
+                ay[b] = gravity * fy[b - b0];
+                az[b] = gravity * fz[b - b0];
+            }
+            list_len[g] = cnt;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Leapfrog.  src/cuda/physics_common.cu:69-147: v_half = v + 0.5*a*dt;
+// x += v_half*dt; reflective walls flip the velocity component and clamp the
+// coordinate; v = (v_half + 0.5*a*dt) * (1 - damp).
+// ---------------------------------------------------------------------------
+static inline void reflect(float &p, float &v, float domain)
+{
+    if (p < 0.0f || p > domain) {
+        v *= -1.0f;
+        p = std::max(0.0f, std::min(domain, p));
+    }
+}
+
+void orc_leapfrog_pos(int n, float dt, float domain, float *x, float *y, float *z,
+                      const float *vx, const float *vy, const float *vz, const float *ax,
+                      const float *ay, const float *az, float *vhx, float *vhy, float *vhz)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        float hx = fmaf(0.5f * ax[i], dt, vx[i]);
+        float hy = fmaf(0.5f * ay[i], dt, vy[i]);
+        float hz = fmaf(0.5f * az[i], dt, vz[i]);
+        float px = fmaf(hx, dt, x[i]);
+        float py = fmaf(hy, dt, y[i]);
+        float pz = fmaf(hz, dt, z[i]);
+        reflect(px, hx, domain);
+        reflect(py, hy, domain);
+        reflect(pz, hz, domain);
+        x[i] = px; y[i] = py; z[i] = pz;
+        vhx[i] = hx; vhy[i] = hy; vhz[i] = hz;
+    }
+}
+
+void orc_leapfrog_vel(int n, float dt, float damp, const float *vhx, const float *vhy,
+                      const float *vhz, const float *ax, const float *ay, const float *az,
+                      float *vx, float *vy, float *vz)
+{
+    const float k = 1.0f - damp;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        vx[i] = fmaf(0.5f * ax[i], dt, vhx[i]) * k;
+        vy[i] = fmaf(0.5f * ay[i], dt, vhy[i]) * k;
+        vz[i] = fmaf(0.5f * az[i], dt, vhz[i]) * k;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Float64 direct sum.  src/cuda/validator.cu:134-174 (compute_ap_forces, self
+// pair included, contributes exactly 0) evaluated in double as the accuracy
+// reference; targets [t0,t1) against all n sources.
+// ---------------------------------------------------------------------------
+void orc_direct_f64(int n, int t0, int t1, const float *x, const float *y, const float *z,
+                    const float *m, double eps2, double gravity, double *ax, double *ay,
+                    double *az)
+{
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int i = t0; i < t1; ++i) {
+        double fx = 0, fy = 0, fz = 0;
+        const double px = x[i], py = y[i], pz = z[i];
+        for (int j = 0; j < n; ++j) {
+            double dx = x[j] - px, dy = y[j] - py, dz = z[j] - pz;
+            double s = dx * dx + dy * dy + dz * dz + eps2;
+            double inv = m[j] / (s * std::sqrt(s));
+            fx += dx * inv; fy += dy * inv; fz += dz * inv;
+        }
+        ax[i - t0] = gravity * fx; ay[i - t0] = gravity * fy; az[i - t0] = gravity * fz;
+    }
+}
+
+// Float32 direct sum in the reference's own arithmetic (validator.cu:134-174),
+// sources in index order; used to check the GPU direct-sum kernel.
+void orc_direct_f32(int n, int t0, int t1, const float *x, const float *y, const float *z,
+                    const float *m, float eps2, float gravity, float *ax, float *ay, float *az)
+{
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int i = t0; i < t1; ++i) {
+        float fx = 0, fy = 0, fz = 0;
+        for (int j = 0; j < n; ++j)
+            pair_force(x[i], y[i], z[i], x[j], y[j], z[j], m[j], fx, fy, fz, eps2);
+        ax[i - t0] = gravity * fx; ay[i - t0] = gravity * fy; az[i - t0] = gravity * fz;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Total energy.  src/cuda/validator.cu:19-36,65-132: sum_i m_i (0.5 v_i^2 -
+// 0.5 G sum_{j!=i} m_j / sqrt(d^2 + eps^2)), in double.
+// ---------------------------------------------------------------------------
+double orc_energy_f64(int n, const float *x, const float *y, const float *z, const float *vx,
+                      const float *vy, const float *vz, const float *m, double eps2,
+                      double gravity)
+{
+    double total = 0;
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : total)
+    for (int i = 0; i < n; ++i) {
+        double e = 0.5 * ((double) vx[i] * vx[i] + (double) vy[i] * vy[i] + (double) vz[i] * vz[i]);
+        double pot = 0;
+        for (int j = 0; j < n; ++j) {
+            if (j == i) continue;
+            double dx = (double) x[j] - x[i], dy = (double) y[j] - y[i], dz = (double) z[j] - z[i];
+            pot += m[j] / std::sqrt(dx * dx + dy * dy + dz * dz + eps2);
+        }
+        e -= 0.5 * gravity * pot;
+        total += e * m[i];
+    }
+    return total;
+}
+
+// Mean and max of |a - a_ref| / |a_ref| (src/cuda/validator.cu:38-63) over k bodies.
+void orc_acc_error(int k, const float *ax, const float *ay, const float *az, const double *rx,
+                   const double *ry, const double *rz, double *mean_out, double *max_out)
+{
+    double sum = 0, mx = 0;
+    for (int i = 0; i < k; ++i) {
+        double dx = ax[i] - rx[i], dy = ay[i] - ry[i], dz = az[i] - rz[i];
+        double e = std::sqrt(dx * dx + dy * dy + dz * dz) /
+                   std::sqrt(rx[i] * rx[i] + ry[i] * ry[i] + rz[i] * rz[i]);
+        sum += e;
+        mx = std::max(mx, e);
+    }
+    *mean_out = sum / k;
+    *max_out = mx;
+}
+
+// ---------------------------------------------------------------------------
+// Whole-step simulation object: the sequencing of Simulation<T>::update()
+// (src/cuda/simulation.cu:75-119,224-238) over the stage functions above.  It
+// is the "multithreaded host build of the same algorithm" timed as the CPU
+// baseline, and the multi-step oracle for trajectory tests.
+// ---------------------------------------------------------------------------
+struct OrcSim {
+    int n, bits, max_codes, group;
+    float theta, dt, gravity, eps, domain, damp;
+    std::vector<float> x, y, z, m, vx, vy, vz, vhx, vhy, vhz, ax, ay, az;
+    std::vector<uint32_t> id;
+    // tree
+    std::vector<uint64_t> codes, sorted, unique;
+    std::vector<int32_t> perm, first_pt, lfc;
+    std::vector<int32_t> first_child, num_children, lb, le, depth, level, pb, pe;
+    std::vector<float> size, comx, comy, comz, mass;
+    std::vector<uint32_t> list_len;
+    int U = 0, M = 0, n_oct = 0;
+    double ms_build = 0, ms_traverse = 0, ms_integrate = 0;
+    uint64_t interactions = 0;
+};
+
+static double now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// update_points + update_octree (src/cuda/simulation.cu:75-102).
+static void orc_sim_build(OrcSim *s, bool permute_all)
+{
+    const int n = s->n;
+    orc_morton(s->x.data(), s->y.data(), s->z.data(), n, s->domain, s->bits, s->codes.data());
+    orc_sort(s->codes.data(), n, s->sorted.data(), s->perm.data());
+    std::vector<float> tf;
+    std::vector<uint32_t> ti;
+    permute(s->x, s->perm, tf); permute(s->y, s->perm, tf); permute(s->z, s->perm, tf);
+    permute(s->m, s->perm, tf);
+    permute(s->vhx, s->perm, tf); permute(s->vhy, s->perm, tf); permute(s->vhz, s->perm, tf);
+    permute(s->id, s->perm, ti);
+    if (permute_all) {  // src/cuda/barnes_hut.cu:577-587 gathers vel and acc too
+        permute(s->vx, s->perm, tf); permute(s->vy, s->perm, tf); permute(s->vz, s->perm, tf);
+        permute(s->ax, s->perm, tf); permute(s->ay, s->perm, tf); permute(s->az, s->perm, tf);
+    }
+    s->U = orc_unique(s->sorted.data(), n, s->unique.data(), s->first_pt.data());
+    s->M = orc_coarsen(s->unique.data(), s->U, s->bits, s->max_codes, s->lfc.data());
+    s->n_oct = orc_build_octree(s->unique.data(), s->U, s->lfc.data(), s->M, s->first_pt.data(),
+                                s->bits, s->domain, s->first_child.data(),
+                                s->num_children.data(), s->lb.data(), s->le.data(),
+                                s->depth.data(), s->level.data(), s->size.data(), s->pb.data(),
+                                s->pe.data());
+    orc_com(s->n_oct, s->first_child.data(), s->num_children.data(), s->pb.data(), s->pe.data(),
+            s->x.data(), s->y.data(), s->z.data(), s->m.data(), s->comx.data(), s->comy.data(),
+            s->comz.data(), s->mass.data());
+}
+
+OrcSim *orc_sim_create(int n, int bits, int max_codes, int group, float theta, float dt,
+                       float gravity, float eps, float domain, float damp, const float *x,
+                       const float *y, const float *z, const float *vx, const float *vy,
+                       const float *vz, const float *m)
+{
+    OrcSim *s = new OrcSim();
+    s->n = n; s->bits = bits; s->max_codes = max_codes; s->group = group;
+    s->theta = theta; s->dt = dt; s->gravity = gravity; s->eps = eps; s->domain = domain;
+    s->damp = damp;
+    auto cp = [&](std::vector<float> &d, const float *src) {
+        d.assign(n, 0.f);
+        if (src) std::memcpy(d.data(), src, sizeof(float) * n);
+    };
+    cp(s->x, x); cp(s->y, y); cp(s->z, z); cp(s->vx, vx); cp(s->vy, vy); cp(s->vz, vz);
+    cp(s->m, m);
+    cp(s->vhx, nullptr); cp(s->vhy, nullptr); cp(s->vhz, nullptr);
+    cp(s->ax, nullptr); cp(s->ay, nullptr); cp(s->az, nullptr);
+    s->id.resize(n);
+    std::iota(s->id.begin(), s->id.end(), 0u);
+    s->codes.resize(n); s->sorted.resize(n); s->unique.resize(n);
+    s->perm.resize(n); s->first_pt.resize(n + 1); s->lfc.resize(n + 1);
+    const int cap = 2 * n;
+    s->first_child.resize(cap); s->num_children.resize(cap); s->lb.resize(cap);
+    s->le.resize(cap); s->depth.resize(cap); s->level.resize(cap); s->pb.resize(cap);
+    s->pe.resize(cap); s->size.resize(cap); s->comx.resize(cap); s->comy.resize(cap);
+    s->comz.resize(cap); s->mass.resize(cap);
+    s->list_len.resize((n + group - 1) / group);
+    // exec_post_spawn (src/cuda/simulation.cu:160-168): sort + tree, no forces.
+    orc_sim_build(s, true);
+    return s;
+}
+
+void orc_sim_destroy(OrcSim *s) { delete s; }
+
+// Simulation<T>::update (src/cuda/simulation.cu:224-238).
+void orc_sim_step(OrcSim *s)
+{
+    double t0 = now_ms();
+    orc_leapfrog_pos(s->n, s->dt, s->domain, s->x.data(), s->y.data(), s->z.data(),
+                     s->vx.data(), s->vy.data(), s->vz.data(), s->ax.data(), s->ay.data(),
+                     s->az.data(), s->vhx.data(), s->vhy.data(), s->vhz.data());
+    double t1 = now_ms();
+    orc_sim_build(s, false);
+    double t2 = now_ms();
+    orc_traverse(s->n, s->group, s->x.data(), s->y.data(), s->z.data(), s->m.data(), s->n_oct,
+                 s->first_child.data(), s->num_children.data(), s->pb.data(), s->pe.data(),
+                 s->size.data(), s->comx.data(), s->comy.data(), s->comz.data(),
+                 s->mass.data(), s->theta, s->eps * s->eps, s->gravity, s->domain,
+                 s->ax.data(), s->ay.data(), s->az.data(), s->list_len.data());
+    double t3 = now_ms();
+    orc_leapfrog_vel(s->n, s->dt, s->damp, s->vhx.data(), s->vhy.data(), s->vhz.data(),
+                     s->ax.data(), s->ay.data(), s->az.data(), s->vx.data(), s->vy.data(),
+                     s->vz.data());
+    double t4 = now_ms();
+    s->ms_integrate = (t1 - t0) + (t4 - t3);
+    s->ms_build = t2 - t1;
+    s->ms_traverse = t3 - t2;
+    uint64_t inter = 0;
+    const int ng = (int) s->list_len.size();
+    for (int g = 0; g < ng; ++g) {
+        int nb = std::min(s->group, s->n - g * s->group);
+        inter += (uint64_t) s->list_len[g] * nb;
+    }
+    s->interactions = inter;
+}
+
+void orc_sim_get_state(OrcSim *s, float *x, float *y, float *z, float *vx, float *vy, float *vz,
+                       float *m, float *ax, float *ay, float *az, uint32_t *id)
+{
+    auto cp = [&](float *d, const std::vector<float> &v) {
+        if (d) std::memcpy(d, v.data(), sizeof(float) * s->n);
+    };
+    cp(x, s->x); cp(y, s->y); cp(z, s->z); cp(vx, s->vx); cp(vy, s->vy); cp(vz, s->vz);
+    cp(m, s->m); cp(ax, s->ax); cp(ay, s->ay); cp(az, s->az);
+    if (id) std::memcpy(id, s->id.data(), sizeof(uint32_t) * s->n);
+}
+
+void orc_sim_get_counts(OrcSim *s, int32_t *U, int32_t *M, int32_t *n_oct,
+                        uint64_t *interactions)
+{
+    *U = s->U; *M = s->M; *n_oct = s->n_oct; *interactions = s->interactions;
+}
+
+void orc_sim_get_timings(OrcSim *s, double *ms_integrate, double *ms_build, double *ms_traverse)
+{
+    *ms_integrate = s->ms_integrate; *ms_build = s->ms_build; *ms_traverse = s->ms_traverse;
+}
+
+int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+}  // extern "C"

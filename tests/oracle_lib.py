@@ -1,0 +1,229 @@
+"""ctypes binding of oracle/liboracle.so -- the host restatement of the reference algorithm.
+
+Test infrastructure only: imported by tests/, __graft_entry__.smoke() and the cpu_baseline
+leg of bench.py, never by the product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-C", ORACLE_DIR], check=True, capture_output=True)
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    L = C.CDLL(LIB_PATH)
+    L.orc_unique.restype = C.c_int
+    L.orc_coarsen.restype = C.c_int
+    L.orc_build_octree.restype = C.c_int
+    L.orc_energy_f64.restype = C.c_double
+    L.orc_sim_create.restype = C.c_void_p
+    L.orc_num_threads.restype = C.c_int
+    _lib = L
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def morton(x, y, z, domain, bits):
+    x, y, z = _f32(x), _f32(y), _f32(z)
+    codes = np.empty(x.size, np.uint64)
+    lib().orc_morton(_p(x), _p(y), _p(z), C.c_int(x.size), C.c_float(domain), C.c_int(bits), _p(codes))
+    return codes
+
+
+def sort(codes):
+    codes = np.ascontiguousarray(codes, np.uint64)
+    out = np.empty_like(codes)
+    perm = np.empty(codes.size, np.int32)
+    lib().orc_sort(_p(codes), C.c_int(codes.size), _p(out), _p(perm))
+    return out, perm
+
+
+def unique(sorted_codes):
+    s = np.ascontiguousarray(sorted_codes, np.uint64)
+    uq = np.empty(s.size, np.uint64)
+    fp = np.empty(s.size + 1, np.int32)
+    U = lib().orc_unique(_p(s), C.c_int(s.size), _p(uq), _p(fp))
+    return uq[:U].copy(), fp[:U + 1].copy()
+
+
+def coarsen(uq, bits, max_codes):
+    uq = np.ascontiguousarray(uq, np.uint64)
+    lfc = np.empty(uq.size + 1, np.int32)
+    M = lib().orc_coarsen(_p(uq), C.c_int(uq.size), C.c_int(bits), C.c_int(max_codes), _p(lfc))
+    return lfc[:M + 1].copy()
+
+
+def build_octree(uq, lfc, first_pt, bits, domain):
+    uq = np.ascontiguousarray(uq, np.uint64)
+    lfc = np.ascontiguousarray(lfc, np.int32)
+    first_pt = np.ascontiguousarray(first_pt, np.int32)
+    M = lfc.size - 1
+    cap = max(2 * M - 1, 1)
+    names_i = ["first_child", "num_children", "leaves_begin", "leaves_end", "depth", "level"]
+    out = {k: np.empty(cap, np.int32) for k in names_i}
+    out["size"] = np.empty(cap, np.float32)
+    out["points_begin"] = np.empty(cap, np.int32)
+    out["points_end"] = np.empty(cap, np.int32)
+    n_oct = lib().orc_build_octree(
+        _p(uq), C.c_int(uq.size), _p(lfc), C.c_int(M), _p(first_pt), C.c_int(bits),
+        C.c_float(domain), _p(out["first_child"]), _p(out["num_children"]),
+        _p(out["leaves_begin"]), _p(out["leaves_end"]), _p(out["depth"]), _p(out["level"]),
+        _p(out["size"]), _p(out["points_begin"]), _p(out["points_end"]))
+    out = {k: v[:n_oct].copy() for k, v in out.items()}
+    out["n_oct"] = n_oct
+    return out
+
+
+def com(tree, x, y, z, m):
+    n_oct = tree["n_oct"]
+    x, y, z, m = _f32(x), _f32(y), _f32(z), _f32(m)
+    out = {k: np.empty(n_oct, np.float32) for k in ("comx", "comy", "comz", "mass")}
+    lib().orc_com(C.c_int(n_oct), _p(tree["first_child"]), _p(tree["num_children"]),
+                  _p(tree["points_begin"]), _p(tree["points_end"]), _p(x), _p(y), _p(z), _p(m),
+                  _p(out["comx"]), _p(out["comy"]), _p(out["comz"]), _p(out["mass"]))
+    return out
+
+
+def traverse(tree, comd, x, y, z, m, group, theta, eps, gravity, domain):
+    x, y, z, m = _f32(x), _f32(y), _f32(z), _f32(m)
+    n = x.size
+    ax, ay, az = (np.empty(n, np.float32) for _ in range(3))
+    ll = np.empty((n + group - 1) // group, np.uint32)
+    a = {k: np.ascontiguousarray(comd[k], np.float32) for k in ("comx", "comy", "comz", "mass")}
+    size = np.ascontiguousarray(tree["size"], np.float32)
+    lib().orc_traverse(C.c_int(n), C.c_int(group), _p(x), _p(y), _p(z), _p(m),
+                       C.c_int(tree["n_oct"]), _p(np.ascontiguousarray(tree["first_child"], np.int32)),
+                       _p(np.ascontiguousarray(tree["num_children"], np.int32)),
+                       _p(np.ascontiguousarray(tree["points_begin"], np.int32)),
+                       _p(np.ascontiguousarray(tree["points_end"], np.int32)), _p(size),
+                       _p(a["comx"]), _p(a["comy"]), _p(a["comz"]), _p(a["mass"]),
+                       C.c_float(theta), C.c_float(np.float32(eps) * np.float32(eps)),
+                       C.c_float(gravity), C.c_float(domain), _p(ax), _p(ay), _p(az), _p(ll))
+    return ax, ay, az, ll
+
+
+def direct_f64(x, y, z, m, eps, gravity, t0=0, t1=None):
+    x, y, z, m = _f32(x), _f32(y), _f32(z), _f32(m)
+    n = x.size
+    t1 = n if t1 is None else t1
+    out = [np.empty(t1 - t0, np.float64) for _ in range(3)]
+    lib().orc_direct_f64(C.c_int(n), C.c_int(t0), C.c_int(t1), _p(x), _p(y), _p(z), _p(m),
+                         C.c_double(float(eps) ** 2), C.c_double(gravity), *[_p(o) for o in out])
+    return out
+
+
+def direct_f32(x, y, z, m, eps, gravity, t0=0, t1=None):
+    x, y, z, m = _f32(x), _f32(y), _f32(z), _f32(m)
+    n = x.size
+    t1 = n if t1 is None else t1
+    out = [np.empty(t1 - t0, np.float32) for _ in range(3)]
+    lib().orc_direct_f32(C.c_int(n), C.c_int(t0), C.c_int(t1), _p(x), _p(y), _p(z), _p(m),
+                         C.c_float(np.float32(eps) * np.float32(eps)), C.c_float(gravity),
+                         *[_p(o) for o in out])
+    return out
+
+
+def energy_f64(x, y, z, vx, vy, vz, m, eps, gravity):
+    a = [_f32(v) for v in (x, y, z, vx, vy, vz, m)]
+    return lib().orc_energy_f64(C.c_int(a[0].size), *[_p(v) for v in a],
+                                C.c_double(float(eps) ** 2), C.c_double(gravity))
+
+
+def acc_error(ax, ay, az, rx, ry, rz):
+    ax, ay, az = _f32(ax), _f32(ay), _f32(az)
+    rx, ry, rz = (np.ascontiguousarray(v, np.float64) for v in (rx, ry, rz))
+    mean, mx = C.c_double(), C.c_double()
+    lib().orc_acc_error(C.c_int(ax.size), _p(ax), _p(ay), _p(az), _p(rx), _p(ry), _p(rz),
+                        C.byref(mean), C.byref(mx))
+    return mean.value, mx.value
+
+
+def leapfrog_pos(dt, domain, x, y, z, vx, vy, vz, ax, ay, az):
+    x, y, z = _f32(x).copy(), _f32(y).copy(), _f32(z).copy()
+    n = x.size
+    vh = [np.empty(n, np.float32) for _ in range(3)]
+    lib().orc_leapfrog_pos(C.c_int(n), C.c_float(dt), C.c_float(domain), _p(x), _p(y), _p(z),
+                           _p(_f32(vx)), _p(_f32(vy)), _p(_f32(vz)), _p(_f32(ax)), _p(_f32(ay)),
+                           _p(_f32(az)), *[_p(v) for v in vh])
+    return x, y, z, vh
+
+
+def full_build(x, y, z, m, domain, bits, max_codes):
+    """Morton -> sort -> unique -> coarsen -> octree -> COM on host arrays."""
+    codes = morton(x, y, z, domain, bits)
+    sorted_codes, perm = sort(codes)
+    xs, ys, zs, ms = (_f32(a)[perm] for a in (x, y, z, m))
+    uq, first_pt = unique(sorted_codes)
+    lfc = coarsen(uq, bits, max_codes)
+    tree = build_octree(uq, lfc, first_pt, bits, domain)
+    comd = com(tree, xs, ys, zs, ms)
+    return dict(codes=codes, codes_sorted=sorted_codes, perm=perm, unique=uq, first_pt=first_pt,
+                leaf_first_code_idx=lfc, tree=tree, com=comd, xs=xs, ys=ys, zs=zs, ms=ms)
+
+
+class OracleSim:
+    """Whole-step host simulation (Simulation<T>::update sequencing over the oracle stages)."""
+
+    def __init__(self, x, y, z, m, vx=None, vy=None, vz=None, *, bits=10, max_codes=32, group=64,
+                 theta=0.75, dt=1e-4, gravity=1.0, eps=1e-3, domain=5.0, damp=0.0):
+        self.n = len(x)
+        arrs = [_f32(a) if a is not None else None for a in (x, y, z, vx, vy, vz, m)]
+        self._h = C.c_void_p(lib().orc_sim_create(
+            C.c_int(self.n), C.c_int(bits), C.c_int(max_codes), C.c_int(group), C.c_float(theta),
+            C.c_float(dt), C.c_float(gravity), C.c_float(eps), C.c_float(domain), C.c_float(damp),
+            *[_p(a) for a in arrs]))
+
+    def step(self):
+        lib().orc_sim_step(self._h)
+
+    def state(self):
+        names = ("x", "y", "z", "vx", "vy", "vz", "m", "ax", "ay", "az")
+        out = {k: np.empty(self.n, np.float32) for k in names}
+        out["id"] = np.empty(self.n, np.uint32)
+        lib().orc_sim_get_state(self._h, *[_p(out[k]) for k in names], _p(out["id"]))
+        return out
+
+    def counts(self):
+        U, M, no, it = C.c_int32(), C.c_int32(), C.c_int32(), C.c_uint64()
+        lib().orc_sim_get_counts(self._h, C.byref(U), C.byref(M), C.byref(no), C.byref(it))
+        return U.value, M.value, no.value, it.value
+
+    def timings(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        lib().orc_sim_get_timings(self._h, C.byref(a), C.byref(b), C.byref(c))
+        return dict(ms_integrate=a.value, ms_build=b.value, ms_traverse=c.value)
+
+    def close(self):
+        if self._h:
+            lib().orc_sim_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,311 @@
+"""CPU tests that pin the host oracle (oracle/oracle.cpp) with hand-checkable cases and
+independent brute-force restatements written here in numpy/Python.
+
+The reference ships no golden vectors for this path (it has no tests at all), so these
+checks -- definitions evaluated the slow, obvious way -- are what the oracle is pinned by.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+
+def spread3_py(u, bits):
+    r = 0
+    for k in range(bits):
+        r |= ((int(u) >> k) & 1) << (3 * k)
+    return r
+
+
+def morton_py(x, y, z, domain, bits):
+    s = np.float32((1 << bits) - 1)
+    out = []
+    for px, py, pz in zip(x, y, z):
+        q = [int(np.float32(np.float32(p) / np.float32(domain)) * s) for p in (px, py, pz)]
+        out.append(spread3_py(q[0], bits) * 4 + spread3_py(q[1], bits) * 2 + spread3_py(q[2], bits))
+    return np.array(out, np.uint64)
+
+
+# ------------------------------------------------------------------ Morton
+@pytest.mark.parametrize("bits", [10, 21])
+def test_morton_corners(bits):
+    d = 4.0
+    top = (1 << bits) - 1
+    x = np.array([0, d, 0, 0, d], np.float32)
+    y = np.array([0, 0, d, 0, d], np.float32)
+    z = np.array([0, 0, 0, d, d], np.float32)
+    c = O.morton(x, y, z, d, bits)
+    sx = spread3_py(top, bits)
+    assert list(c) == [0, sx * 4, sx * 2, sx, sx * 7]
+    # x is the most significant bit of each triple
+    assert c[1] > c[2] > c[3]
+    assert int(c[4]) == (1 << (3 * bits)) - 1
+
+
+@pytest.mark.parametrize("bits", [10, 21])
+def test_morton_matches_definition(bits):
+    rng = np.random.default_rng(1)
+    x, y, z = (rng.uniform(0, 5, 2000).astype(np.float32) for _ in range(3))
+    assert np.array_equal(O.morton(x, y, z, 5.0, bits), morton_py(x, y, z, 5.0, bits))
+
+
+# ------------------------------------------------------------------ sort / unique
+def test_sort_is_stable():
+    rng = np.random.default_rng(2)
+    codes = rng.integers(0, 50, 5000).astype(np.uint64)
+    s, perm = O.sort(codes)
+    ref = np.argsort(codes, kind="stable")
+    assert np.array_equal(perm, ref)
+    assert np.array_equal(s, codes[ref])
+
+
+def test_unique_and_first_point():
+    s = np.array([3, 3, 3, 7, 9, 9, 12], np.uint64)
+    uq, fp = O.unique(s)
+    assert list(uq) == [3, 7, 9, 12]
+    assert list(fp) == [0, 3, 4, 6, 7]
+    rng = np.random.default_rng(3)
+    s = np.sort(rng.integers(0, 300, 4000).astype(np.uint64))
+    uq, fp = O.unique(s)
+    ru, ri = np.unique(s, return_index=True)
+    assert np.array_equal(uq, ru) and np.array_equal(fp[:-1], ri) and fp[-1] == s.size
+
+
+# ------------------------------------------------------------------ leaf coarsening
+def coarsen_py(uq, bits, max_codes):
+    """Leaves = largest cells with <= max_codes codes, capped at the cell in which a code
+    is alone w.r.t. its neighbours; keep the first code of every leaf."""
+    kb = 3 * bits
+    U = len(uq)
+    if U <= max_codes:
+        return np.array([0, U], np.int32)
+    u = [int(v) for v in uq]
+
+    def lcp(a, b):
+        x = a ^ b
+        return kb if x == 0 else kb - x.bit_length()
+
+    heads = []
+    for i in range(U):
+        l1 = lcp(u[i], u[i - 1]) // 3 if i > 0 else -1
+        l2 = lcp(u[i], u[i + 1]) // 3 if i < U - 1 else -1
+        ld = max(l1, l2) + 1
+        acc_first = i          # first code of the accepted cell (the code itself at ld)
+        for t in range(ld - 1, -1, -1):
+            sh = kb - 3 * t
+            pre = u[i] >> sh
+            lo = np.searchsorted(uq, np.uint64(pre << sh), "left")
+            hi = np.searchsorted(uq, np.uint64(((pre + 1) << sh) - 1), "right")
+            if hi - lo > max_codes:
+                break
+            acc_first = lo
+        if acc_first == i:
+            heads.append(i)
+    return np.array(heads + [U], np.int32)
+
+
+@pytest.mark.parametrize("bits,max_codes", [(10, 4), (10, 32), (21, 8), (21, 32)])
+def test_coarsen_matches_definition(bits, max_codes):
+    rng = np.random.default_rng(4)
+    n = 3000
+    # clustered points -> varied leaf depths
+    c = rng.uniform(1, 4, (6, 3))
+    pts = (c[rng.integers(0, 6, n)] + rng.normal(0, 0.05, (n, 3))).clip(0, 5).astype(np.float32)
+    codes = np.unique(O.morton(pts[:, 0], pts[:, 1], pts[:, 2], 5.0, bits))
+    lfc = O.coarsen(codes, bits, max_codes)
+    assert np.array_equal(lfc, coarsen_py(codes, bits, max_codes))
+    assert lfc[0] == 0 and lfc[-1] == codes.size and np.all(np.diff(lfc) > 0)
+    assert np.diff(lfc).max() <= max_codes
+
+
+def test_coarsen_single_leaf_cases():
+    # U <= max: one root leaf (the reference loops forever here)
+    uq = np.array([5, 9, 1000], np.uint64)
+    assert list(O.coarsen(uq, 10, 32)) == [0, 3]
+    assert list(O.coarsen(np.array([77], np.uint64), 21, 1)) == [0, 1]
+
+
+def test_coarsen_eight_octants():
+    # one code in each octant of the root, max 1 -> 8 singleton leaves; max 8 -> single leaf
+    bits = 10
+    uq = np.array([o << (3 * (bits - 1)) for o in range(8)], np.uint64)
+    assert list(O.coarsen(uq, bits, 1)) == list(range(9))
+    assert list(O.coarsen(uq, bits, 8)) == [0, 8]
+    # two tight clusters of 3 codes in octants 0 and 7, max 3 -> two leaves
+    uq = np.array([0, 1, 2, (7 << 27), (7 << 27) + 1, (7 << 27) + 2], np.uint64)
+    assert list(O.coarsen(uq, bits, 3)) == [0, 3, 6]
+
+
+# ------------------------------------------------------------------ octree
+def octree_py(leaf_keys, bits):
+    """Compressed octree over sorted distinct keys, built recursively from the definition;
+    returns arrays in depth-major, Morton-minor (BFS) order."""
+    kb = 3 * bits
+    keys = [int(k) for k in leaf_keys]
+
+    def lcp(a, b):
+        x = a ^ b
+        return kb if x == 0 else kb - x.bit_length()
+
+    nodes = []  # dict(lb, le, level, depth, children)
+
+    def make(lb, le, depth, parent_level):
+        if lb == le:
+            return dict(lb=lb, le=le, level=parent_level + 1, depth=depth, children=[])
+        level = lcp(keys[lb], keys[le]) // 3
+        sh = kb - 3 * (level + 1)
+        kids, start = [], lb
+        for j in range(lb + 1, le + 2):
+            if j == le + 1 or (keys[j] >> sh) != (keys[start] >> sh):
+                kids.append((start, j - 1))
+                start = j
+        node = dict(lb=lb, le=le, level=level, depth=depth, children=[])
+        node["children"] = [make(a, b, depth + 1, level) for a, b in kids]
+        return node
+
+    root = make(0, len(keys) - 1, 0, -1)
+    if len(keys) == 1:
+        root["level"] = 0
+    frontier, order = [root], []
+    while frontier:
+        order.extend(frontier)
+        frontier = [c for nd in frontier for c in nd["children"]]
+    ids = {id(nd): i for i, nd in enumerate(order)}
+    out = dict(first_child=[], num_children=[], leaves_begin=[], leaves_end=[], depth=[], level=[])
+    for nd in order:
+        out["first_child"].append(ids[id(nd["children"][0])] if nd["children"] else -1)
+        out["num_children"].append(len(nd["children"]))
+        out["leaves_begin"].append(nd["lb"])
+        out["leaves_end"].append(nd["le"])
+        out["depth"].append(nd["depth"])
+        out["level"].append(nd["level"])
+    return {k: np.array(v, np.int32) for k, v in out.items()}
+
+
+@pytest.mark.parametrize("bits,max_codes,n", [(10, 1, 500), (10, 8, 3000), (21, 1, 700), (21, 32, 6000)])
+def test_octree_matches_definition(bits, max_codes, n):
+    rng = np.random.default_rng(5)
+    c = rng.uniform(1, 4, (5, 3))
+    pts = (c[rng.integers(0, 5, n)] + rng.normal(0, 0.08, (n, 3))).clip(0, 5).astype(np.float32)
+    m = np.ones(n, np.float32)
+    b = O.full_build(pts[:, 0], pts[:, 1], pts[:, 2], m, 5.0, bits, max_codes)
+    tree = b["tree"]
+    lk = b["unique"][b["leaf_first_code_idx"][:-1]]
+    ref = octree_py(lk, bits)
+    assert tree["n_oct"] == ref["depth"].size
+    for k in ref:
+        assert np.array_equal(tree[k], ref[k]), k
+    # size = domain / 2^level, point ranges tile [0, n)
+    assert np.array_equal(tree["size"], (np.float32(5.0) / (2.0 ** tree["level"])).astype(np.float32))
+    leaf = tree["num_children"] == 0
+    pb, pe = tree["points_begin"][leaf], tree["points_end"][leaf]
+    o = np.argsort(pb)
+    assert pb[o][0] == 0 and pe[o][-1] == n - 1 and np.array_equal(pb[o][1:], pe[o][:-1] + 1)
+    # every particle of a node lies inside the node's cube
+    xs, ys, zs = b["xs"], b["ys"], b["zs"]
+    q = (b["codes_sorted"][tree["points_begin"]] >> np.uint64(0))
+    for o_ in rng.integers(0, tree["n_oct"], 50):
+        sh = np.uint64(3 * (bits - int(tree["level"][o_])))
+        cs = b["codes_sorted"][tree["points_begin"][o_]:tree["points_end"][o_] + 1]
+        assert np.all((cs >> sh) == (cs[0] >> sh))
+
+
+def test_octree_two_points_and_root_leaf():
+    # two far points, max 1: root + 2 leaves
+    x = np.array([0.1, 4.9], np.float32)
+    b = O.full_build(x, x, x, np.ones(2, np.float32), 5.0, 10, 1)
+    t = b["tree"]
+    assert t["n_oct"] == 3 and list(t["num_children"]) == [2, 0, 0] and list(t["first_child"]) == [1, -1, -1]
+    assert list(t["depth"]) == [0, 1, 1] and list(t["level"]) == [0, 1, 1]
+    # all points identical -> U = 1 -> single root leaf holding everything
+    x = np.full(10, 2.5, np.float32)
+    b = O.full_build(x, x, x, np.ones(10, np.float32), 5.0, 21, 32)
+    t = b["tree"]
+    assert t["n_oct"] == 1 and t["num_children"][0] == 0
+    assert t["points_begin"][0] == 0 and t["points_end"][0] == 9
+    assert b["com"]["mass"][0] == 10.0 and b["com"]["comx"][0] == np.float32(2.5)
+
+
+# ------------------------------------------------------------------ COM / forces
+def test_com_against_float64():
+    rng = np.random.default_rng(6)
+    n = 5000
+    pts = rng.uniform(0.5, 4.5, (n, 3)).astype(np.float32)
+    m = rng.uniform(0.5, 2.0, n).astype(np.float32)
+    b = O.full_build(pts[:, 0], pts[:, 1], pts[:, 2], m, 5.0, 21, 8)
+    t, c = b["tree"], b["com"]
+    for o in list(range(0, t["n_oct"], 37)) + [0]:
+        sl = slice(t["points_begin"][o], t["points_end"][o] + 1)
+        mm = b["ms"][sl].astype(np.float64)
+        assert np.isclose(c["mass"][o], mm.sum(), rtol=1e-5)
+        for ax_, arr in (("comx", b["xs"]), ("comy", b["ys"]), ("comz", b["zs"])):
+            assert np.isclose(c[ax_][o], (mm * arr[sl]).sum() / mm.sum(), rtol=2e-5)
+
+
+def test_two_body_force_and_energy():
+    x = np.array([2.0, 3.0], np.float32)
+    y = z = np.array([2.5, 2.5], np.float32)
+    m = np.array([2.0, 3.0], np.float32)
+    eps, G = 0.1, 1.5
+    ax, ay, az = O.direct_f64(x, y, z, m, eps, G)
+    s = 1.0 + eps * eps
+    assert np.allclose(ax, [G * 3.0 / s ** 1.5, -G * 2.0 / s ** 1.5]) and np.allclose(ay, 0) and np.allclose(az, 0)
+    v0 = np.zeros(2, np.float32)
+    e = O.energy_f64(x, y, z, np.array([1, 0], np.float32), v0, v0, m, eps, G)
+    assert np.isclose(e, 0.5 * 2.0 * 1.0 - G * 2.0 * 3.0 / np.sqrt(s))
+
+
+@pytest.mark.parametrize("group", [32, 64])
+def test_traversal_theta_zero_is_direct_sum(group):
+    rng = np.random.default_rng(7)
+    n = 1000  # not a multiple of the group size: ragged last group
+    pts = rng.uniform(1.5, 3.5, (n, 3)).astype(np.float32)
+    m = rng.uniform(0.5, 1.5, n).astype(np.float32)
+    b = O.full_build(pts[:, 0], pts[:, 1], pts[:, 2], m, 5.0, 21, 4)
+    ax, ay, az, ll = O.traverse(b["tree"], b["com"], b["xs"], b["ys"], b["zs"], b["ms"], group,
+                                0.0, 0.05, 1.0, 5.0)
+    assert np.all(ll == n)  # every group interacts with every particle exactly once
+    rx, ry, rz = O.direct_f64(b["xs"], b["ys"], b["zs"], b["ms"], 0.05, 1.0)
+    mean, mx = O.acc_error(ax, ay, az, rx, ry, rz)
+    assert mx < 2e-5
+
+
+def test_traversal_accuracy_matches_published_band():
+    """32k disk, eps=0.01, G=32: the reference plots mean relative acceleration error
+    ~1.7e-4 / 4.5-6e-4 / 0.9-1.5e-3 at theta = 0.3 / 0.5 / 0.7
+    (plots/disk-acc-32k-eps0.01-dt0.001.png)."""
+    import nbody_amd as nb
+    ic = nb.sample_ic(nb.IC_DISK, 32768, 42)
+    b = O.full_build(ic["x"], ic["y"], ic["z"], ic["m"], 5.0, 21, 32)
+    rx, ry, rz = O.direct_f64(b["xs"], b["ys"], b["zs"], b["ms"], 0.01, 1.0)
+    for theta, lo, hi in ((0.3, 0.5e-4, 2.5e-4), (0.5, 2e-4, 8e-4), (0.7, 5e-4, 2e-3)):
+        ax, ay, az, _ = O.traverse(b["tree"], b["com"], b["xs"], b["ys"], b["zs"], b["ms"], 32,
+                                   theta, 0.01, 1.0, 5.0)
+        mean, _ = O.acc_error(ax, ay, az, rx, ry, rz)
+        assert lo < mean < hi, (theta, mean)
+
+
+def test_leapfrog_reflects_at_walls():
+    x = np.array([0.05, 4.95, 2.0], np.float32)
+    v = np.array([-1.0, 1.0, 0.5], np.float32)
+    zero = np.zeros(3, np.float32)
+    px, py, pz, vh = O.leapfrog_pos(0.1, 5.0, x, x, x, v, v, v, zero, zero, zero)
+    assert px[0] == 0.0 and vh[0][0] == 1.0      # clamped, velocity flipped
+    assert px[1] == 5.0 and vh[0][1] == -1.0
+    assert np.isclose(px[2], 2.05) and vh[0][2] == np.float32(0.5)
+
+
+def test_sim_step_conserves_momentum_roughly():
+    import nbody_amd as nb
+    ic = nb.sample_ic(nb.IC_SPHERE, 4096, 1)
+    sim = O.OracleSim(ic["x"], ic["y"], ic["z"], ic["m"] / 4096, bits=21, group=64, theta=0.5,
+                      dt=1e-3, eps=0.05)
+    for _ in range(3):
+        sim.step()
+    s = sim.state()
+    U, M, no, inter = sim.counts()
+    assert U <= 4096 and M <= U and no >= M and inter > 0
+    p = np.array([(s["m"].astype(np.float64) * s[k]).sum() for k in ("vx", "vy", "vz")])
+    scale = (s["m"].astype(np.float64) * np.sqrt(s["vx"] ** 2 + s["vy"] ** 2 + s["vz"] ** 2)).sum()
+    assert np.linalg.norm(p) < 2e-2 * scale
+    assert sorted(s["id"]) == list(range(4096))
