@@ -415,6 +415,8 @@ __global__ __launch_bounds__(256) void k_com(const Counts *counts,
                                                             __HIP_MEMORY_SCOPE_AGENT);
             const int nc = o_num_children[parent];
             if ((int) arrived != nc - 1) break;
+            // every child has arrived: leave the counter at 0 for the next build
+            __hip_atomic_store(&counter[parent], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int fc = o_first_child[parent];
             sx = sy = sz = sm = 0.f;
             for (int c = fc; c < fc + nc; ++c) {

@@ -149,15 +149,19 @@ def test_first_update_matches_oracle(bits, group, kind, n, theta):
                                 ref1["ms"], group, theta, eps, G, 5.0)
     # identical tree + identical COM bits -> identical interaction lists
     assert np.array_equal(gpu["list_len"], ll)
-    # same sources, different summation order and hardware rsqrt: |da| <= 2e-5 |a|
+    # same sources, but float32 sums of up to ~1e4 terms taken in a different order and the
+    # hardware v_rsq_f32 (1 ulp) instead of 1/sqrtf: |da| <= 1e-4 |a| for every body,
+    # 1e-5 on average
     err = np.sqrt((st["ax"] - ax) ** 2 + (st["ay"] - ay) ** 2 + (st["az"] - az) ** 2)
     ref_n = np.sqrt(ax.astype(np.float64) ** 2 + ay ** 2 + az ** 2)
-    assert (err / ref_n).max() < 2e-5
+    assert (err / ref_n).max() < 1e-4 and (err / ref_n).mean() < 1e-5
     # velocity kick from the GPU's own accelerations is exact
     p1 = ref1["perm"]
     for k, a, h in (("vx", st["ax"], vh[0][p1]), ("vy", st["ay"], vh[1][p1]), ("vz", st["az"], vh[2][p1])):
-        want = (np.float32(0.5) * a * np.float32(dt) + h).astype(np.float32)
-        assert np.allclose(st[k], want, rtol=1e-6, atol=1e-7), k
+        kick = 0.5 * a.astype(np.float64) * np.float64(np.float32(dt))
+        want = kick + h
+        # one float32 rounding of 0.5*a, one of the fused multiply-add
+        assert np.all(np.abs(st[k] - want) <= 2e-7 * (np.abs(kick) + np.abs(h)) + 1e-30), k
 
 
 @pytest.mark.parametrize("bits", [10, 21])
