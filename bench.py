@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the Barnes-Hut step on MI355X.
+
+Workload (BASELINE.json configs[3], the README's "~150 ms/step" case): 2,097,152-particle
+cold uniform sphere (r = 0.5, centred in a domain of 5.0, m = 1, eps = 0.1, dt = 1e-6,
+the reference's SPAWN_SPHERE parameters), theta = 0.6, 32 codes per leaf, wave64 groups.
+A step is one Simulation::update(): kick-drift + Morton, radix sort, tree build, COM,
+traversal, kick.  Synthetic data, generated on the host before the timed region; every
+input is resident in HBM when timing starts.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): weak scaling with
+2,097,152 particles per GPU.  Every rank holds the whole particle set and builds the same
+tree; the traversal -- the dominant cost -- is sharded by Morton-contiguous group ranges and
+the accelerations are exchanged with one all-gather per step.
+
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_PER_GPU = 2_097_152
+THETA = 0.6
+EPS = 0.1
+DT = 1e-6
+FLOP_PER_INTERACTION = 20          # GPU-Gems/Nyland convention for one softened pair force
+BUILD_BYTES_PER_PARTICLE = 300     # algorithmic bytes of integrate+sort+permute+build+COM
+PEAK_FP32_TFLOPS = 157.3           # MI355X FP32 vector peak
+PEAK_HBM_GBS = 8000.0              # MI355X HBM3E peak
+REFERENCE_MS_PER_STEP = 150.0      # reference README, RTX 500 Ada, 2,097,152 particles, theta=0.6
+
+
+class _DevArray:
+    """Zero-copy view of library-owned device memory for torch (CUDA array interface)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False),
+                                         "version": 2}
+
+
+def cpu_baseline(ic, bits, steps=1):
+    """The host oracle (same algorithm, same parameters) timed on this machine's cores on
+    `steps` steps of the full 2,097,152-particle workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    cores = O.lib().orc_num_threads()
+    t0 = time.time()
+    sim = O.OracleSim(ic["x"], ic["y"], ic["z"], ic["m"], bits=bits, max_codes=32, group=64,
+                      theta=THETA, dt=DT, gravity=1.0, eps=EPS, domain=5.0)
+    spawn_s = time.time() - t0
+    ms, inter, tb, tt = [], 0, 0.0, 0.0
+    for _ in range(steps):
+        t0 = time.time()
+        sim.step()
+        ms.append((time.time() - t0) * 1e3)
+        tm = sim.timings()
+        tb += tm["ms_build"]
+        tt += tm["ms_traverse"]
+        inter = sim.counts()[3]
+    sim.close()
+    mean = sum(ms) / len(ms)
+    return {"value": round(mean, 1), "unit": "ms/step", "cores": cores, "kind": "port",
+            "sample": f"{steps} step(s) of the full {len(ic['x'])}-particle workload after the "
+                      f"spawn build ({spawn_s:.1f} s); OpenMP traversal/integrate, serial sort+tree",
+            "build_ms": round(tb / steps, 1), "traversal_ms": round(tt / steps, 1),
+            "interactions_per_s": round(inter / (tt / steps / 1e3)) if tt > 0 else None}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--morton-bits", type=int, default=int(os.environ.get("NBODY_MORTON_BITS", "10")))
+    ap.add_argument("--particles-per-gpu", type=int, default=N_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import nbody_amd as nb
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with "
+                             "python -m torch.distributed.run --nproc-per-node N\n")
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        sys.stderr.write("bench.py needs a GPU (no CPU fallback)\n")
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n = args.particles_per_gpu * world
+    group = 64
+    ngroups = (n + group - 1) // group
+    assert ngroups % world == 0, "groups must divide evenly over the ranks"
+    ic = nb.sample_ic(nb.IC_SPHERE, n, 42)
+    params = nb.Params(num_points=n, max_num_codes_per_leaf=32, traversal_group_size=group,
+                       theta=THETA, dt=DT, gravity=1.0, softening_factor=EPS, domain_size=5.0,
+                       morton_bits=args.morton_bits, device_id=local_rank, flags=nb.FLAG_TIMING)
+    sim = nb.Simulation(params)
+    sim.set_state(ic["x"], ic["y"], ic["z"], ic["m"])
+    U, M, n_oct = sim.tree_counts()
+
+    acc = None
+    if world > 1:
+        g0 = rank * (ngroups // world)
+        g1 = g0 + ngroups // world
+        sim.set_traversal_range(g0, g1)
+        v = sim.device_view()
+        acc = [torch.as_tensor(_DevArray(p, n), device=f"cuda:{local_rank}") for p in (v.ax, v.ay, v.az)]
+        b0, b1 = g0 * group, min(g1 * group, n)
+
+    def one_step():
+        sim.update()
+        if world > 1:
+            sim.sync()  # traversal done on the library's stream before RCCL reads the slices
+            for a in acc:
+                dist.all_gather_into_tensor(a, a[b0:b1])
+            torch.cuda.current_stream().synchronize()
+            sim.finish_step()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    done = 0
+    while done < args.warmup:
+        one_step()
+        done += 1
+    fence()
+    if args.warmup:
+        sim.get_timings()  # drop warm-up records
+    tim = dict(steps=0, ms_integrate=0.0, ms_sort=0.0, ms_build=0.0, ms_com=0.0, ms_traverse=0.0,
+               ms_total=0.0, interactions=0)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step()
+        if (i + 1) % 48 == 0 and i + 1 < args.steps:  # event ring holds 64 steps
+            t = sim.get_timings()
+            for k in tim:
+                tim[k] += t[k]
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = sim.get_timings()
+    for k in tim:
+        tim[k] += t[k]
+    if world > 1:
+        red = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(red, op=dist.ReduceOp.MAX)
+        elapsed = float(red.item())
+        it = torch.tensor([tim["interactions"]], dtype=torch.int64, device=f"cuda:{local_rank}")
+        dist.all_reduce(it, op=dist.ReduceOp.SUM)
+        total_inter = int(it.item())
+    else:
+        total_inter = int(tim["interactions"])
+    st = sim.get_state()
+    ok = bool(np.isfinite(st["ax"]).all() and np.isfinite(st["x"]).all())
+    sim.close()
+
+    if rank == 0:
+        K = max(args.steps, 1)
+        ms_step = elapsed * 1e3 / K
+        trav_ms = tim["ms_traverse"] / K
+        build_ms = (tim["ms_integrate"] + tim["ms_sort"] + tim["ms_build"] + tim["ms_com"]) / K
+        inter_step_rank0 = tim["interactions"] / K
+        tflops = FLOP_PER_INTERACTION * inter_step_rank0 / (trav_ms * 1e-3) / 1e12 if trav_ms else 0.0
+        build_gbs = BUILD_BYTES_PER_PARTICLE * n / (build_ms * 1e-3) / 1e9 if build_ms else 0.0
+        out = {
+            "metric": "ms/step (build+traversal) at 2M particles theta=0.6",
+            "value": round(ms_step, 4),
+            "unit": "ms/step",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 4),
+            "higher_is_better": False,
+            "scaling": "weak",
+            "vs_baseline": round(ms_step / REFERENCE_MS_PER_STEP, 5) if world == 1 else None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "cold uniform sphere r=0.5 in domain 5.0 (SPAWN_SPHERE), "
+                                   f"{args.particles_per_gpu} particles/GPU, theta=0.6, eps=0.1, "
+                                   "dt=1e-6, 32 codes/leaf, group=64",
+                       "particles": n, "morton_bits": args.morton_bits,
+                       "parallelism": "single" if world == 1 else
+                       f"replicated build, traversal sharded over {world} Morton ranges, "
+                       "all-gather of accelerations",
+                       "tree": {"unique_codes": U, "leaves": M, "octree_nodes": n_oct}},
+            "build_ms": round(build_ms, 4),
+            "traversal_ms": round(trav_ms, 4),
+            "stage_ms": {k[3:]: round(tim[k] / K, 4) for k in
+                         ("ms_integrate", "ms_sort", "ms_build", "ms_com", "ms_traverse")},
+            "interactions_per_step": round(total_inter / K),
+            "interactions_per_s": round(total_inter / elapsed),
+            "finite": ok,
+            "baseline_note": "vs_baseline = ms/step / 150 ms (reference README, RTX 500 Ada "
+                             "laptop GPU; different hardware)",
+            "roofline": {"bound": "valu", "kernel": "k_traverse", "achieved": round(tflops, 2),
+                         "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tflops / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                         "note": "20 FLOP x exact interaction count / mean kernel time (HIP "
+                                 "events on the library stream); FP32 vector peak, MFMA unused"},
+            "roofline_build": {"bound": "hbm", "achieved": round(build_gbs, 1), "peak": PEAK_HBM_GBS,
+                               "unit": "GB/s", "frac": round(build_gbs / PEAK_HBM_GBS, 4),
+                               "note": "300 algorithmic B/particle over integrate+sort+build+COM"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ic, args.morton_bits)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
