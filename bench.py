@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--morton-bits", type=int, default=int(os.environ.get("NBODY_MORTON_BITS", "10")))
     ap.add_argument("--particles-per-gpu", type=int, default=N_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--walk-only", action="store_true",
+                    help="profiling aid: skip the force arithmetic (results meaningless)")
     args = ap.parse_args()
 
     import numpy as np
@@ -114,7 +116,8 @@ def main():
     ic = nb.sample_ic(nb.IC_SPHERE, n, 42)
     params = nb.Params(num_points=n, max_num_codes_per_leaf=32, traversal_group_size=group,
                        theta=THETA, dt=DT, gravity=1.0, softening_factor=EPS, domain_size=5.0,
-                       morton_bits=args.morton_bits, device_id=local_rank, flags=nb.FLAG_TIMING)
+                       morton_bits=args.morton_bits, device_id=local_rank,
+                       flags=nb.FLAG_TIMING | (nb.FLAG_DEBUG_WALK_ONLY if args.walk_only else 0))
     sim = nb.Simulation(params)
     sim.set_state(ic["x"], ic["y"], ic["z"], ic["m"])
     U, M, n_oct = sim.tree_counts()

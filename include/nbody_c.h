@@ -37,7 +37,10 @@ enum {
 /* nbody_params.flags */
 enum {
     NBODY_FLAG_TIMING = 1u << 0,       /* record per-stage HIP events every step             */
-    NBODY_FLAG_NO_FUSED_VEL = 1u << 1  /* run the velocity half-kick as its own kernel        */
+    NBODY_FLAG_NO_FUSED_VEL = 1u << 1, /* run the velocity half-kick as its own kernel        */
+    NBODY_FLAG_DEBUG_WALK_ONLY = 1u << 8 /* profiling aid: traversal walks the tree and fills
+                                            its source lists but skips the force arithmetic
+                                            (accelerations are meaningless)                  */
 };
 
 /* The first 11 fields are Simulation<T>::Params, same order and meaning

@@ -20,6 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libnbody_mi355.so")
 OK = 0
 FLAG_TIMING = 1 << 0
 FLAG_NO_FUSED_VEL = 1 << 1
+FLAG_DEBUG_WALK_ONLY = 1 << 8
 
 IC_UNIFORM, IC_SPHERE, IC_DISK, IC_PLUMMER = 0, 1, 2, 3
 

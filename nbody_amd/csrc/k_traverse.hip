@@ -12,16 +12,28 @@
 //     node's children become candidates;
 //   * acc = gravity * sum m_j d / (|d|^2 + eps^2)^(3/2).
 // Design here: one wave64 per group, no workgroup barriers, no global-memory queues.
-// Candidates live on a per-wave LDS stack; each round pops up to 64 of them, one per
-// lane, and every lane tests its node against the 64 group bodies (broadcast LDS reads).
-// Accepted (com, mass) records and the particles of leaf nodes are appended to one LDS
-// source list; whenever it holds >= 64 entries each lane (= one body) runs the force
-// loop over 64 broadcast entries.  The set of sources a group interacts with is
-// independent of the pop order, so list lengths match the breadth-first reference walk.
+//   * Inner-node candidates live on a per-wave LDS stack.  Each round pops up to 64 of them,
+//     one per lane, and every lane tests its node against the group's bodies (broadcast
+//     LDS reads, two bodies per packed-FP32 instruction).
+//   * Accepted (com, mass) records go to an LDS source list.  Children of opened nodes are
+//     split by the parent's child-leaf mask: inner children return to the node stack, leaf
+//     children go to a separate LDS leaf stack and never pay for a distance test.
+//   * Leaves are expanded 64 at a time: a wave scan of their particle counts, then every
+//     lane locates "its" particle of the concatenated ranges by a 6-step search, so each
+//     global load instruction brings in 64 particles; the next chunk's load is issued
+//     before the current chunk's forces are evaluated.
+//   * Whenever the source list holds >= 64 entries each lane (= one body) runs the force
+//     loop over 32 broadcast entry PAIRS: v_pk_{add,mul,fma}_f32 evaluate two sources per
+//     instruction, v_rsq_f32 once per source.
+// The set of sources a group interacts with does not depend on the order candidates are
+// visited in, so list lengths equal those of the reference's breadth-first walk.
 #include "dev_utils.hpp"
 #include "nbody_internal.hpp"
 
 namespace nb {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int TRAV_RESERVE = 7 * 24;  // single-pop fallback never needs more than 7/level
 
@@ -38,7 +50,20 @@ __device__ __forceinline__ void interact(const Float4 s, float px, float py, flo
     fz = fmaf(dz, inv, fz);
 }
 
-template <int G, bool FUSE_VEL>
+// Per-wave LDS working set (7936 B).  Bodies and sources are stored as PAIRS,
+// (x0,x1,y0,y1) and (z0,z1[,m0,m1]), so that one 64-bit register pair feeds one packed op.
+struct alignas(16) WaveLds {
+    v4f bxy[32];
+    v2f bz[32];
+    v4f lxy[64];   // source ring: 128 entries = 64 pairs
+    v4f lzm[64];
+    int stack[TRAV_STACK];
+    int leaf[TRAV_LEAF_STACK];
+    int lpre[64];
+    int lpb[64];
+};
+
+template <int G, bool FUSE_VEL, bool WALK_ONLY>
 __global__ __launch_bounds__(64 * TRAV_WAVES) void k_traverse(
     int n, int g0, int g1, const Float4 *__restrict__ posm, const Float4 *__restrict__ nodeA,
     const NodeB *__restrict__ nodeB, float theta, float eps2, float gravity, float domain,
@@ -47,104 +72,183 @@ __global__ __launch_bounds__(64 * TRAV_WAVES) void k_traverse(
     const float *__restrict__ vhy, const float *__restrict__ vhz, float *__restrict__ vx,
     float *__restrict__ vy, float *__restrict__ vz, uint32_t *err)
 {
-    __shared__ Float4 s_body[TRAV_WAVES][64];
-    __shared__ Float4 s_list[TRAV_WAVES][128];
-    __shared__ int s_stack[TRAV_WAVES][TRAV_STACK];
+    __shared__ WaveLds lds[TRAV_WAVES];
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int lblk = xcd_remap((int) blockIdx.x, (int) gridDim.x);
     const int g = g0 + lblk * TRAV_WAVES + w;
     if (g >= g1) return;
-    Float4 *body = s_body[w];
-    Float4 *list = s_list[w];
-    int *stack = s_stack[w];
+    WaveLds &L = lds[w];
+    float *bxyf = reinterpret_cast<float *>(L.bxy);
+    float *bzf = reinterpret_cast<float *>(L.bz);
+    float *lxyf = reinterpret_cast<float *>(L.lxy);
+    float *lzmf = reinterpret_cast<float *>(L.lzm);
 
     const int b = g * G + lane;
     const bool active = lane < G && b < n;
     const Float4 me = posm[active ? b : g * G];
-    if (lane < G) body[lane] = me;
-    if (lane == 0) stack[0] = 0;
+    if (lane < G) {
+        const int p = lane >> 1, h = lane & 1;
+        bxyf[4 * p + h] = me.x;
+        bxyf[4 * p + 2 + h] = me.y;
+        bzf[2 * p + h] = me.z;
+    }
+    int sp = 0, leaf_n = 0;
+    {
+        const bool root_leaf = (nodeB[0].meta & NODE_LEAF) != 0u;
+        if (lane == 0) { L.stack[0] = 0; L.leaf[0] = 0; }
+        if (root_leaf) leaf_n = 1; else sp = 1;
+    }
     __builtin_amdgcn_wave_barrier();
 
-    float fx = 0.f, fy = 0.f, fz = 0.f;
-    int list_n = 0;
+    v2f fx2 = {0.f, 0.f}, fy2 = {0.f, 0.f}, fz2 = {0.f, 0.f};
+    const v2f px2 = {me.x, me.x}, py2 = {me.y, me.y}, pz2 = {me.z, me.z};
+    const v2f e2 = {eps2, eps2};
+    int head = 0, list_n = 0;   // source ring: entries [head, head + list_n) mod 128
     uint32_t total = 0;
-    int sp = 1;
     const float th2 = theta * theta;
     const float dinit = domain * domain * 3.0f;
 
+    auto pair_force = [&](const v4f a, const v4f c) {
+        if (WALK_ONLY) {  // profiling aid: keep the LDS reads alive, skip the arithmetic
+            fx2 += a.xy; fy2 += c.xy;
+            return;
+        }
+        const v2f dx = a.xy - px2, dy = a.zw - py2, dz = c.xy - pz2;
+        const v2f s = __builtin_elementwise_fma(
+            dz, dz, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dx, dx, e2)));
+        const v2f s3 = s * s * s;
+        v2f inv = {__builtin_amdgcn_rsqf(s3.x), __builtin_amdgcn_rsqf(s3.y)};
+        inv *= c.zw;
+        fx2 = __builtin_elementwise_fma(dx, inv, fx2);
+        fy2 = __builtin_elementwise_fma(dy, inv, fy2);
+        fz2 = __builtin_elementwise_fma(dz, inv, fz2);
+    };
+    auto write_entry = [&](int e, const Float4 v) {
+        const int p = e >> 1, h = e & 1;
+        lxyf[4 * p + h] = v.x;
+        lxyf[4 * p + 2 + h] = v.y;
+        lzmf[4 * p + h] = v.z;
+        lzmf[4 * p + 2 + h] = v.w;
+    };
     auto flush64 = [&]() {
         __builtin_amdgcn_wave_barrier();
-        const Float4 *e = list + (list_n - 64);
+        const int hp = head >> 1;
 #pragma unroll 8
-        for (int j = 0; j < 64; ++j) interact(e[j], me.x, me.y, me.z, eps2, fx, fy, fz);
+        for (int j = 0; j < 32; ++j) pair_force(L.lxy[hp + j], L.lzm[hp + j]);
+        head ^= 64;
         list_n -= 64;
         __builtin_amdgcn_wave_barrier();
     };
 
-    while (sp > 0) {
+    // Expand up to 64 leaves from the leaf stack into the source ring.
+    auto process_leaves = [&]() {
+        const int cnt = min(64, leaf_n);
+        const bool valid = lane < cnt;
+        const int id = valid ? L.leaf[leaf_n - 1 - lane] : 0;
+        leaf_n -= cnt;
+        const NodeB Bl = nodeB[id];
+        const uint32_t np = valid ? (uint32_t) Bl.count : 0u;
+        const uint32_t inc = wave_incl_scan_u32(np);
+        const int P = (int) __shfl(inc, 63, 64);
+        L.lpre[lane] = (int) (inc - np);
+        L.lpb[lane] = Bl.first;
+        total += (uint32_t) P;
+        __builtin_amdgcn_wave_barrier();
+        auto fetch = [&](int c0) -> Float4 {
+            const int idx = c0 + lane;
+            Float4 v = Float4{0.f, 0.f, 0.f, 0.f};
+            if (idx < P) {
+                int j = 0;
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1)
+                    if (L.lpre[j + step] <= idx) j += step;
+                v = posm[L.lpb[j] + (idx - L.lpre[j])];
+            }
+            return v;
+        };
+        Float4 nxt = fetch(0);
+        for (int c0 = 0; c0 < P; c0 += 64) {
+            const Float4 cur = nxt;
+            if (c0 + 64 < P) nxt = fetch(c0 + 64);
+            const int c = min(64, P - c0);
+            if (lane < c) write_entry((head + list_n + lane) & 127, cur);
+            list_n += c;
+            if (list_n >= 64) flush64();
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    while (true) {
+        while (leaf_n >= 64 || (sp == 0 && leaf_n > 0)) process_leaves();
+        if (sp == 0) break;
+
         const int room = TRAV_STACK - TRAV_RESERVE - sp;
         const int k = min(min(sp, 64), max(room / 7, 1));
         const bool valid = lane < k;
-        const int node = valid ? stack[sp - 1 - lane] : 0;
+        const int node = valid ? L.stack[sp - 1 - lane] : 0;
         sp -= k;
         const Float4 A = nodeA[node];
         const NodeB B = nodeB[node];
-        const bool leaf = valid && B.leaf != 0;
-        const bool inner = valid && B.leaf == 0;
 
+        // d2min over the group's bodies, two per packed instruction
+        const v2f ax2 = {A.x, A.x}, ay2 = {A.y, A.y}, az2 = {A.z, A.z};
         float dmin = dinit;
 #pragma unroll 8
-        for (int j = 0; j < G; ++j) {
-            const Float4 q = body[j];
-            const float dx = q.x - A.x, dy = q.y - A.y, dz = q.z - A.z;
-            const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-            dmin = d <= dmin ? d : dmin;
+        for (int j = 0; j < G / 2; ++j) {
+            const v4f q = L.bxy[j];
+            const v2f qz = L.bz[j];
+            const v2f dx = q.xy - ax2, dy = q.zw - ay2, dz = qz - az2;
+            const v2f d = __builtin_elementwise_fma(
+                dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+            dmin = fminf(dmin, fminf(d.x, d.y));
         }
-        const bool approx = inner && (__fdiv_rn(B.size * B.size, dmin) < th2);
-        const bool open = inner && !approx;
+        const bool approx = valid && (__fdiv_rn(B.size * B.size, dmin) < th2);
+        const bool open = valid && !approx;
 
-        // accepted nodes -> source list
+        // accepted nodes -> source ring
         const unsigned long long am = __ballot(approx);
-        if (approx) list[list_n + mbcnt(am)] = A;
+        if (approx) write_entry((head + list_n + mbcnt(am)) & 127, A);
         const int na = (int) __popcll(am);
         list_n += na;
         total += (uint32_t) na;
 
-        // opened nodes -> children onto the stack
-        const uint32_t cnt = open ? (uint32_t) B.count : 0u;
-        const uint32_t inc = wave_incl_scan_u32(cnt);
-        const int tot = (int) __shfl(inc, 63, 64);
-        if (sp + tot > TRAV_STACK) {  // cannot happen by construction; never write past LDS
-            if (lane == 0) atomicOr(err, (uint32_t) DEV_ERR_STACK);
+        // opened nodes -> inner children to the node stack, leaf children to the leaf stack
+        const uint32_t nc = open ? (uint32_t) B.count : 0u;
+        const uint32_t lmask = open ? (B.meta & 0xffu) : 0u;
+        const uint32_t cl = (uint32_t) __popc(lmask);
+        const uint32_t packed = (nc - cl) | (cl << 16);
+        const uint32_t inc = wave_incl_scan_u32(packed);
+        const uint32_t tot = (uint32_t) __shfl(inc, 63, 64);
+        const uint32_t exc = inc - packed;
+        const int tot_i = (int) (tot & 0xffffu), tot_l = (int) (tot >> 16);
+        if (sp + tot_i > TRAV_STACK || leaf_n + tot_l > TRAV_LEAF_STACK) {
+            if (lane == 0) atomicOr(err, (uint32_t) DEV_ERR_STACK);  // unreachable by construction
             break;
         }
-        const int dst = sp + (int) (inc - cnt);
-        for (uint32_t c = 0; c < cnt; ++c) stack[dst + (int) c] = B.first + (int) c;
-        sp += tot;
+        int di = sp + (int) (exc & 0xffffu), dl = leaf_n + (int) (exc >> 16);
+        for (uint32_t c = 0; c < nc; ++c) {
+            const int child = B.first + (int) c;
+            if ((lmask >> c) & 1u) L.leaf[dl++] = child; else L.stack[di++] = child;
+        }
+        sp += tot_i;
+        leaf_n += tot_l;
+        __builtin_amdgcn_wave_barrier();
 
         if (list_n >= 64) flush64();
-
-        // leaf nodes -> their particles into the source list
-        unsigned long long lm = __ballot(leaf);
-        while (lm) {
-            const int src = (int) __builtin_ctzll(lm);
-            lm &= lm - 1;
-            const int pb = __shfl(B.first, src, 64);
-            const int np = __shfl(B.count, src, 64);
-            for (int o = 0; o < np; o += 64) {
-                const int c = min(64, np - o);
-                if (lane < c) list[list_n + lane] = posm[pb + o + lane];
-                list_n += c;
-                total += (uint32_t) c;
-                if (list_n >= 64) flush64();
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
     }
-    // remainder (< 64 entries)
+
+    // remainder (< 64 entries): pad an odd tail with a massless source
+    if (list_n & 1) {
+        if (lane == 0) write_entry((head + list_n) & 127, Float4{0.f, 0.f, 0.f, 0.f});
+    }
     __builtin_amdgcn_wave_barrier();
-    for (int j = 0; j < list_n; ++j) interact(list[j], me.x, me.y, me.z, eps2, fx, fy, fz);
+    {
+        const int hp = head >> 1;
+        const int np2 = (list_n + 1) >> 1;
+        for (int j = 0; j < np2; ++j) pair_force(L.lxy[hp + j], L.lzm[hp + j]);
+    }
+    const float fx = fx2.x + fx2.y, fy = fy2.x + fy2.y, fz = fz2.x + fz2.y;
 
     if (lane == 0) list_len[g] = total;
     if (active) {
@@ -220,16 +324,19 @@ hipError_t launch_traverse(Sim *s, bool fuse_vel)
         const int grid = (g1 - g0 + TRAV_WAVES - 1) / TRAV_WAVES;
         const float eps2 = s->p.softening_factor * s->p.softening_factor;
         const float keep = 1.0f - s->p.velocity_dampening;
-#define NB_TRAV(GG, FV)                                                                          \
-    hipLaunchKernelGGL((k_traverse<GG, FV>), dim3(grid), dim3(64 * TRAV_WAVES), 0, s->stream,    \
+#define NB_TRAV(GG, FV, WO)                                                                        \
+    hipLaunchKernelGGL((k_traverse<GG, FV, WO>), dim3(grid), dim3(64 * TRAV_WAVES), 0, s->stream,    \
                        s->n, g0, g1, s->posm, s->nodeA, s->nodeB, s->p.theta, eps2,              \
                        s->p.gravity, s->p.domain_size, s->ax, s->ay, s->az, s->list_len,         \
                        s->p.dt, keep, s->vhx[c], s->vhy[c], s->vhz[c], s->vx[c], s->vy[c],       \
                        s->vz[c], &s->counts->err)
-        if (s->group == 64) {
-            if (fuse_vel) NB_TRAV(64, true); else NB_TRAV(64, false);
+        const bool walk_only = (s->p.flags & NBODY_FLAG_DEBUG_WALK_ONLY) != 0;
+        if (walk_only) {
+            if (s->group == 64) NB_TRAV(64, false, true); else NB_TRAV(32, false, true);
+        } else if (s->group == 64) {
+            if (fuse_vel) NB_TRAV(64, true, false); else NB_TRAV(64, false, false);
         } else {
-            if (fuse_vel) NB_TRAV(32, true); else NB_TRAV(32, false);
+            if (fuse_vel) NB_TRAV(32, true, false); else NB_TRAV(32, false, false);
         }
 #undef NB_TRAV
     }

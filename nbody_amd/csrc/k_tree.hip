@@ -357,7 +357,13 @@ __global__ __launch_bounds__(256) void k_emit(
         o_pb[o] = pb;
         o_pe[o] = pe;
         o_parent[o] = parent;
-        nodeB[o] = leaf ? NodeB{size, pb, pe - pb + 1, 1} : NodeB{size, fc, nc, 0};
+        uint32_t meta = NODE_LEAF;
+        if (!leaf) {
+            meta = 0;
+            for (int c = 0; c < nc; ++c)
+                if ((bfs[fc + c] & 1u) == 0u) meta |= 1u << c;
+        }
+        nodeB[o] = leaf ? NodeB{size, pb, pe - pb + 1, meta} : NodeB{size, fc, nc, meta};
     }
 }
 

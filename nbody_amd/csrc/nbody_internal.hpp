@@ -17,13 +17,17 @@ constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 4;                       // elements per thread in compaction tiles
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 constexpr int TRAV_WAVES = 4;                       // groups (waves) per traversal workgroup
-constexpr int TRAV_STACK = 1024;                    // LDS node stack entries per wave
+constexpr int TRAV_STACK = 512;                     // LDS inner-node stack entries per wave
+constexpr int TRAV_LEAF_STACK = 640;                // LDS leaf stack entries per wave
 constexpr int MAX_DEPTH_BINS = 256;                 // depth key space of the node ranking pass
 constexpr int TIMING_RING = 64;
 enum { EV_BEGIN = 0, EV_INTEGRATE, EV_SORT, EV_BUILD, EV_COM, EV_TRAVERSE, EV_COUNT };
 
 struct Float4 { float x, y, z, w; };
-struct NodeB { float size; int32_t first; int32_t count; int32_t leaf; };
+// Traversal record of an octree node.  Leaf: first/count = particle range, meta = NODE_LEAF.
+// Inner node: first/count = child range, meta bit c set iff child c is a leaf.
+struct NodeB { float size; int32_t first; int32_t count; uint32_t meta; };
+constexpr uint32_t NODE_LEAF = 0x80000000u;
 
 // Device-resident counters written by the build kernels (one int each).
 struct Counts {
