@@ -112,6 +112,15 @@ int nbody_get_num_octree_nodes(nbody_t *sim, int32_t *out);
 /* Simulation::write_validation_history() (include/simulation.hpp:37,
  * src/cuda/validator.cu:322-353): CSV `sys_energy,sys_energy_ap,avg_acc_err`. */
 int nbody_write_validation_history(nbody_t *sim, const char *csv_path);
+/* The same records as arrays (up to `capacity`); *count = records available.  With
+ * num_steps_validator > 0 every nbody_update() appends one record (and synchronises):
+ * total energy of the tree run, total energy of an all-pairs twin run advanced by direct
+ * sums (Validator<T>, src/cuda/validator.cu:238-320), and the step-local mean relative
+ * acceleration error of the tree forces against a direct sum at the same positions
+ * (metric of src/cuda/validator.cu:38-63).  The record index wraps at num_steps_validator
+ * like the reference's curr_step_. */
+int nbody_get_validation_history(nbody_t *sim, double *sys_energy, double *sys_energy_ap,
+                                 double *avg_acc_err, int32_t capacity, int32_t *count);
 
 /* Current particle state in the CURRENT (Morton-sorted) order; id[i] is the index the
  * particle had when it was spawned / set.  Any pointer may be NULL.  The reference has

@@ -79,6 +79,7 @@ EXPORTS = [
     "nbody_get_num_octree_nodes", "nbody_write_validation_history", "nbody_get_state",
     "nbody_get_device_ptrs", "nbody_get_tree_counts", "nbody_get_octree", "nbody_get_timings",
     "nbody_direct_sum_dev", "nbody_direct_sum", "nbody_set_traversal_range", "nbody_finish_step",
+    "nbody_get_validation_history",
 ]
 
 _lib = None
@@ -122,6 +123,9 @@ def load_library() -> C.CDLL:
                                          C.c_void_p]
     lib.nbody_direct_sum.argtypes = [C.c_void_p] + [fp] * 3
     lib.nbody_set_traversal_range.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    dp = C.POINTER(C.c_double)
+    lib.nbody_get_validation_history.argtypes = [C.c_void_p, dp, dp, dp, C.c_int32,
+                                                 C.POINTER(C.c_int32)]
     _lib = lib
     return lib
 
@@ -228,6 +232,18 @@ class Simulation:
 
     def write_validation_history(self, csv_file_path: str):
         self._check(self._lib.nbody_write_validation_history(self._h, csv_file_path.encode()))
+
+    def validation_history(self) -> dict:
+        """Arrays sys_energy, sys_energy_ap, avg_acc_err (one entry per validated step)."""
+        cap = max(self.params.num_steps_validator, 1)
+        e, ea, er = (np.zeros(cap, np.float64) for _ in range(3))
+        cnt = C.c_int32()
+        dp = C.POINTER(C.c_double)
+        self._check(self._lib.nbody_get_validation_history(
+            self._h, e.ctypes.data_as(dp), ea.ctypes.data_as(dp), er.ctypes.data_as(dp), cap,
+            C.byref(cnt)))
+        k = cnt.value
+        return {"sys_energy": e[:k], "sys_energy_ap": ea[:k], "avg_acc_err": er[:k]}
 
     # -- additions -----------------------------------------------------------
     def sync(self):

@@ -15,10 +15,6 @@
 
 #include "nbody_internal.hpp"
 
-namespace nb {
-hipError_t launch_count_interactions(Sim *s, unsigned long long *out);
-}
-
 using namespace nb;
 
 namespace {
@@ -57,6 +53,8 @@ void free_all(Sim *s)
     F(s->bfs); F(s->octid); F(s->o_depth); F(s->o_first_child); F(s->o_num_children); F(s->o_lb);
     F(s->o_le); F(s->o_level); F(s->o_pb); F(s->o_pe); F(s->o_parent); F(s->o_size); F(s->o_wsum);
     F(s->nodeA); F(s->nodeB); F(s->list_len); F(s->inter_dev);
+    F(s->tw_posm); F(s->tw_pot); F(s->ds_pot);
+    for (int k = 0; k < 3; ++k) { F(s->tw_v[k]); F(s->tw_vh[k]); F(s->tw_a[k]); F(s->ds_a[k]); }
     if (s->counts_host) (void) hipHostFree(s->counts_host);
     for (int r = 0; r < TIMING_RING; ++r)
         for (int k = 0; k < EV_COUNT; ++k)
@@ -129,6 +127,14 @@ int alloc_all(Sim *s)
     NB_HIP(s, hipMemsetAsync(s->list_len, 0, std::max<size_t>(ngroups, 1) * 4, s->stream));
     NB_HIP(s, dalloc(&s->inter_dev, (size_t) TIMING_RING));
     NB_HIP(s, hipMemsetAsync(s->inter_dev, 0, TIMING_RING * 8, s->stream));
+    if (s->p.num_steps_validator > 0) {
+        NB_HIP(s, dalloc(&s->tw_posm, n)); NB_HIP(s, dalloc(&s->tw_pot, n));
+        NB_HIP(s, dalloc(&s->ds_pot, n));
+        for (int k = 0; k < 3; ++k) {
+            NB_HIP(s, dalloc(&s->tw_v[k], n)); NB_HIP(s, dalloc(&s->tw_vh[k], n));
+            NB_HIP(s, dalloc(&s->tw_a[k], n)); NB_HIP(s, dalloc(&s->ds_a[k], n));
+        }
+    }
     if (s->p.flags & NBODY_FLAG_TIMING)
         for (int r = 0; r < TIMING_RING; ++r)
             for (int k = 0; k < EV_COUNT; ++k) NB_HIP(s, hipEventCreate(&s->ev[r][k]));
@@ -271,6 +277,7 @@ int post_spawn(Sim *s)
     s->pending_vel = false;
     s->ev_pending = 0;
     s->hist_e.clear(); s->hist_e_ap.clear(); s->hist_err.clear();
+    s->val_count = 0;
     return fetch_counts(s);
 }
 
@@ -295,6 +302,22 @@ int upload_state(Sim *s, const float *x, const float *y, const float *z, const f
     NB_HIP(s, hipMemsetAsync(s->vhy[c], 0, b, s->stream));
     NB_HIP(s, hipMemsetAsync(s->vhz[c], 0, b, s->stream));
     NB_HIP(s, hipMemcpyAsync(s->id[c], ids.data(), b, hipMemcpyHostToDevice, s->stream));
+    std::vector<Float4> tw;
+    if (s->p.num_steps_validator > 0) {
+        // Validator::copy_initial_conditions (src/cuda/validator.cu:226-236): the all-pairs
+        // twin starts from the same particles, zero accelerations; it keeps spawn order.
+        tw.resize(n);
+        for (size_t i = 0; i < n; ++i) tw[i] = Float4{x[i], y[i], z[i], m[i]};
+        NB_HIP(s, hipMemcpyAsync(s->tw_posm, tw.data(), n * sizeof(Float4), hipMemcpyHostToDevice,
+                                 s->stream));
+        const float *vsrc[3] = {vx, vy, vz};
+        for (int k = 0; k < 3; ++k) {
+            if (vsrc[k]) NB_HIP(s, hipMemcpyAsync(s->tw_v[k], vsrc[k], b, hipMemcpyHostToDevice, s->stream));
+            else NB_HIP(s, hipMemsetAsync(s->tw_v[k], 0, b, s->stream));
+            NB_HIP(s, hipMemsetAsync(s->tw_a[k], 0, b, s->stream));
+        }
+        s->val_step = 0;
+    }
     NB_HIP(s, hipStreamSynchronize(s->stream));  // host staging buffers go out of scope
     return post_spawn(s);
 }
@@ -308,6 +331,67 @@ int spawn(Sim *s, int kind, float p0, float p1)
     if (rc) return fail(s, rc, "unknown initial condition kind");
     return upload_state(s, x.data(), y.data(), z.data(), vx.data(), vy.data(), vz.data(),
                         m.data());
+}
+
+// One validator record (reference: Validator<T>::update_all_pairs, src/cuda/validator.cu:238-320,
+// metric definitions :19-63).  Differences, on purpose: the relative acceleration error is
+// STEP-LOCAL (tree forces against a direct sum at the same positions; the reference compares
+// against its separately evolving twin), and a record is taken after a step, not before it.
+//   sys_energy    = sum_i m_i (v_i^2/2 - G/2 sum_{j!=i} m_j / sqrt(d^2+eps^2)) of the tree run
+//   sys_energy_ap = the same for the all-pairs twin, advanced by the same leapfrog
+//   avg_acc_err   = mean_i |a_tree - a_direct| / |a_direct|
+int validator_step(Sim *s)
+{
+    const int n = s->n;
+    const size_t b = (size_t) n * 4;
+    const int c = s->cur;
+    const float eps2 = s->p.softening_factor * s->p.softening_factor;
+    const float G = s->p.gravity;
+    NB_HIP(s, launch_direct_pot(s->posm, n, s->posm, n, eps2, G, s->ds_a[0], s->ds_a[1], s->ds_a[2],
+                                s->ds_pot, 1, s->stream));
+    NB_HIP(s, launch_twin_kick_drift(n, s->p.dt, s->p.domain_size, s->tw_posm, s->tw_v[0],
+                                     s->tw_v[1], s->tw_v[2], s->tw_a[0], s->tw_a[1], s->tw_a[2],
+                                     s->tw_vh[0], s->tw_vh[1], s->tw_vh[2], s->stream));
+    NB_HIP(s, launch_direct_pot(s->tw_posm, n, s->tw_posm, n, eps2, G, s->tw_a[0], s->tw_a[1],
+                                s->tw_a[2], s->tw_pot, 1, s->stream));
+    NB_HIP(s, launch_vel_kick_raw(n, s->p.dt, 1.0f - s->p.velocity_dampening, s->tw_vh[0],
+                                  s->tw_vh[1], s->tw_vh[2], s->tw_a[0], s->tw_a[1], s->tw_a[2],
+                                  s->tw_v[0], s->tw_v[1], s->tw_v[2], s->stream));
+    std::vector<float> a[3], d[3], v[3], tv[3], pot(n), tpot(n), m(n);
+    std::vector<Float4> tp(n);
+    const float *acc[3] = {s->ax, s->ay, s->az};
+    const float *vel[3] = {s->vx[c], s->vy[c], s->vz[c]};
+    for (int k = 0; k < 3; ++k) {
+        a[k].resize(n); d[k].resize(n); v[k].resize(n); tv[k].resize(n);
+        NB_HIP(s, hipMemcpyAsync(a[k].data(), acc[k], b, hipMemcpyDeviceToHost, s->stream));
+        NB_HIP(s, hipMemcpyAsync(d[k].data(), s->ds_a[k], b, hipMemcpyDeviceToHost, s->stream));
+        NB_HIP(s, hipMemcpyAsync(v[k].data(), vel[k], b, hipMemcpyDeviceToHost, s->stream));
+        NB_HIP(s, hipMemcpyAsync(tv[k].data(), s->tw_v[k], b, hipMemcpyDeviceToHost, s->stream));
+    }
+    NB_HIP(s, hipMemcpyAsync(pot.data(), s->ds_pot, b, hipMemcpyDeviceToHost, s->stream));
+    NB_HIP(s, hipMemcpyAsync(tpot.data(), s->tw_pot, b, hipMemcpyDeviceToHost, s->stream));
+    NB_HIP(s, hipMemcpyAsync(m.data(), s->m[c], b, hipMemcpyDeviceToHost, s->stream));
+    NB_HIP(s, hipMemcpyAsync(tp.data(), s->tw_posm, (size_t) n * sizeof(Float4), hipMemcpyDeviceToHost,
+                             s->stream));
+    NB_HIP(s, hipStreamSynchronize(s->stream));
+    double e = 0, e_ap = 0, err = 0;
+    for (int i = 0; i < n; ++i) {
+        const double v2 = (double) v[0][i] * v[0][i] + (double) v[1][i] * v[1][i] + (double) v[2][i] * v[2][i];
+        e += m[i] * (0.5 * v2 - 0.5 * G * pot[i]);
+        const double w2 = (double) tv[0][i] * tv[0][i] + (double) tv[1][i] * tv[1][i] + (double) tv[2][i] * tv[2][i];
+        e_ap += tp[i].w * (0.5 * w2 - 0.5 * G * tpot[i]);
+        const double dx = a[0][i] - d[0][i], dy = a[1][i] - d[1][i], dz = a[2][i] - d[2][i];
+        const double dn = std::sqrt((double) d[0][i] * d[0][i] + (double) d[1][i] * d[1][i] + (double) d[2][i] * d[2][i]);
+        if (dn > 0) err += std::sqrt(dx * dx + dy * dy + dz * dz) / dn;
+    }
+    const size_t cap = (size_t) s->p.num_steps_validator;
+    if (s->hist_e.size() < cap) { s->hist_e.resize(cap); s->hist_e_ap.resize(cap); s->hist_err.resize(cap); }
+    s->hist_e[s->val_step] = e;
+    s->hist_e_ap[s->val_step] = e_ap;
+    s->hist_err[s->val_step] = err / n;
+    s->val_step = (s->val_step + 1) % s->p.num_steps_validator;  // wraps like the reference
+    if (s->val_count < (int) cap) s->val_count++;
+    return NBODY_OK;
 }
 
 struct DevGuard {
@@ -456,6 +540,7 @@ int nbody_update(nbody_t *h)
         s->ev_pending++;
     }
     if (sharded) s->pending_vel = true;
+    if (s->p.num_steps_validator > 0 && !sharded) return validator_step(s);
     return NBODY_OK;
 }
 
@@ -668,8 +753,24 @@ int nbody_write_validation_history(nbody_t *h, const char *csv_path)
     std::ofstream out(csv_path);
     if (!out) return fail(s, NBODY_ERR_IO, std::string("cannot open ") + csv_path);
     out << "sys_energy,sys_energy_ap,avg_acc_err" << std::endl;
-    for (size_t i = 0; i < s->hist_e.size(); ++i)
+    out.precision(9);
+    for (int i = 0; i < s->val_count; ++i)
         out << s->hist_e[i] << "," << s->hist_e_ap[i] << "," << s->hist_err[i] << std::endl;
+    return out ? NBODY_OK : fail(s, NBODY_ERR_IO, "write failed");
+}
+
+int nbody_get_validation_history(nbody_t *h, double *sys_energy, double *sys_energy_ap,
+                                 double *avg_acc_err, int32_t capacity, int32_t *count)
+{
+    NB_ENTER(h);
+    if (!count) return fail(s, NBODY_ERR_INVALID, "null count");
+    const int k = std::min<int>(s->val_count, capacity < 0 ? 0 : capacity);
+    for (int i = 0; i < k; ++i) {
+        if (sys_energy) sys_energy[i] = s->hist_e[i];
+        if (sys_energy_ap) sys_energy_ap[i] = s->hist_e_ap[i];
+        if (avg_acc_err) avg_acc_err[i] = s->hist_err[i];
+    }
+    *count = s->val_count;
     return NBODY_OK;
 }
 

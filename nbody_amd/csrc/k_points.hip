@@ -153,7 +153,50 @@ __global__ __launch_bounds__(256) void k_vel_kick(int n, float dt, float keep,
     vz[i] = fmaf(0.5f * az[i], dt, vhz[i]) * keep;
 }
 
+// Kick-drift of the all-pairs twin (no Morton code; positions live in the packed record).
+__global__ __launch_bounds__(256) void k_twin_kick_drift(int n, float dt, float domain,
+                                                         Float4 *__restrict__ posm,
+                                                         const float *__restrict__ vx,
+                                                         const float *__restrict__ vy,
+                                                         const float *__restrict__ vz,
+                                                         const float *__restrict__ ax,
+                                                         const float *__restrict__ ay,
+                                                         const float *__restrict__ az,
+                                                         float *__restrict__ vhx,
+                                                         float *__restrict__ vhy,
+                                                         float *__restrict__ vhz)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Float4 p = posm[i];
+    float hx = fmaf(0.5f * ax[i], dt, vx[i]);
+    float hy = fmaf(0.5f * ay[i], dt, vy[i]);
+    float hz = fmaf(0.5f * az[i], dt, vz[i]);
+    p.x = fmaf(hx, dt, p.x);
+    p.y = fmaf(hy, dt, p.y);
+    p.z = fmaf(hz, dt, p.z);
+    reflect(p.x, hx, domain);
+    reflect(p.y, hy, domain);
+    reflect(p.z, hz, domain);
+    posm[i] = p;
+    vhx[i] = hx; vhy[i] = hy; vhz[i] = hz;
+}
+
 static inline int nblk(int n, int t) { return (n + t - 1) / t; }
+
+hipError_t launch_twin_kick_drift(int n, float dt, float domain, Float4 *posm, const float *vx,
+                                  const float *vy, const float *vz, const float *ax,
+                                  const float *ay, const float *az, float *vhx, float *vhy,
+                                  float *vhz, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_twin_kick_drift, dim3(nblk(n, 256)), dim3(256), 0, st, n, dt, domain, posm,
+                       vx, vy, vz, ax, ay, az, vhx, vhy, vhz);
+    return hipGetLastError();
+}
+
+hipError_t launch_vel_kick_raw(int n, float dt, float keep, const float *vhx, const float *vhy,
+                               const float *vhz, const float *ax, const float *ay, const float *az,
+                               float *vx, float *vy, float *vz, hipStream_t st);
 
 hipError_t launch_integrate_morton(Sim *s)
 {
@@ -207,6 +250,15 @@ hipError_t launch_permute(Sim *s, bool all_fields)
     // the velocity kick that ends the step overwrites all of them.
     s->cur = o;
     return hipSuccess;
+}
+
+hipError_t launch_vel_kick_raw(int n, float dt, float keep, const float *vhx, const float *vhy,
+                               const float *vhz, const float *ax, const float *ay, const float *az,
+                               float *vx, float *vy, float *vz, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_vel_kick, dim3(nblk(n, 256)), dim3(256), 0, st, n, dt, keep, vhx, vhy, vhz,
+                       ax, ay, az, vx, vy, vz);
+    return hipGetLastError();
 }
 
 hipError_t launch_vel_kick(Sim *s)

@@ -284,22 +284,38 @@ __global__ __launch_bounds__(256) void k_count_interactions(int n, int group, in
 
 // ---------------------------------------------------------------------------
 // Direct sum: 256 targets per workgroup, sources staged through LDS 256 at a time.
+// POT additionally accumulates pot_i = sum_j m_j / sqrt(|d|^2 + eps^2); with self_pairs
+// set (targets and sources are the same array) the j = i term is removed again, which is
+// exact because that term is m_i * rsq(eps^2) on both sides.
 // ---------------------------------------------------------------------------
+template <bool POT>
 __global__ __launch_bounds__(256) void k_direct(const Float4 *__restrict__ targets, int nt,
                                                 const Float4 *__restrict__ sources, int ns,
                                                 float eps2, float gravity, float *__restrict__ ax,
                                                 float *__restrict__ ay, float *__restrict__ az,
-                                                int accumulate)
+                                                int accumulate, float *__restrict__ pot,
+                                                int self_pairs)
 {
     __shared__ Float4 s_src[256];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const Float4 me = targets[i < nt ? i : 0];
-    float fx = 0.f, fy = 0.f, fz = 0.f;
+    float fx = 0.f, fy = 0.f, fz = 0.f, ps = 0.f;
     for (int t0 = 0; t0 < ns; t0 += 256) {
         const int c = min(256, ns - t0);
         if ((int) threadIdx.x < c) s_src[threadIdx.x] = sources[t0 + threadIdx.x];
         __syncthreads();
-        if (c == 256) {
+        if (POT) {
+            for (int j = 0; j < c; ++j) {
+                const Float4 s = s_src[j];
+                const float dx = s.x - me.x, dy = s.y - me.y, dz = s.z - me.z;
+                const float t = fmaf(dz, dz, fmaf(dy, dy, dx * dx)) + eps2;
+                const float r = __builtin_amdgcn_rsqf(t);
+                const float mr = s.w * r;
+                ps += mr;
+                const float inv = mr * r * r;
+                fx = fmaf(dx, inv, fx); fy = fmaf(dy, inv, fy); fz = fmaf(dz, inv, fz);
+            }
+        } else if (c == 256) {
 #pragma unroll 8
             for (int j = 0; j < 256; ++j) interact(s_src[j], me.x, me.y, me.z, eps2, fx, fy, fz);
         } else {
@@ -311,6 +327,10 @@ __global__ __launch_bounds__(256) void k_direct(const Float4 *__restrict__ targe
         float rx = gravity * fx, ry = gravity * fy, rz = gravity * fz;
         if (accumulate) { rx += ax[i]; ry += ay[i]; rz += az[i]; }
         ax[i] = rx; ay[i] = ry; az[i] = rz;
+        if (POT) {
+            if (self_pairs) ps -= me.w * __builtin_amdgcn_rsqf(eps2);
+            pot[i] = accumulate ? pot[i] + ps : ps;
+        }
     }
 }
 
@@ -358,8 +378,18 @@ hipError_t launch_direct(const Float4 *targets, int nt, const Float4 *sources, i
                          hipStream_t st)
 {
     if (nt <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_direct, dim3((nt + 255) / 256), dim3(256), 0, st, targets, nt, sources, ns,
-                       eps2, gravity, ax, ay, az, accumulate);
+    hipLaunchKernelGGL(k_direct<false>, dim3((nt + 255) / 256), dim3(256), 0, st, targets, nt,
+                       sources, ns, eps2, gravity, ax, ay, az, accumulate, (float *) nullptr, 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_direct_pot(const Float4 *targets, int nt, const Float4 *sources, int ns,
+                             float eps2, float gravity, float *ax, float *ay, float *az,
+                             float *pot, int self_pairs, hipStream_t st)
+{
+    if (nt <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_direct<true>, dim3((nt + 255) / 256), dim3(256), 0, st, targets, nt,
+                       sources, ns, eps2, gravity, ax, ay, az, 0, pot, self_pairs);
     return hipGetLastError();
 }
 

@@ -110,7 +110,11 @@ struct Sim {
     hipEvent_t ev[TIMING_RING][EV_COUNT]{};
     int ev_head = 0, ev_pending = 0;
     uint64_t *inter_dev = nullptr;   // [TIMING_RING] interactions per step
-    // validator history
+    // validator: all-pairs twin simulation (state in spawn order) + history
+    Float4 *tw_posm = nullptr;
+    float *tw_v[3]{}, *tw_vh[3]{}, *tw_a[3]{}, *tw_pot = nullptr;
+    float *ds_a[3]{}, *ds_pot = nullptr;   // direct sum at the Barnes-Hut positions
+    int val_step = 0, val_count = 0;
     std::vector<double> hist_e, hist_e_ap, hist_err;
 };
 
@@ -126,5 +130,17 @@ hipError_t launch_vel_kick(Sim *s);
 hipError_t launch_direct(const Float4 *targets, int nt, const Float4 *sources, int ns, float eps2,
                          float gravity, float *ax, float *ay, float *az, int accumulate,
                          hipStream_t st);
+
+hipError_t launch_direct_pot(const Float4 *targets, int nt, const Float4 *sources, int ns,
+                             float eps2, float gravity, float *ax, float *ay, float *az,
+                             float *pot, int self_pairs, hipStream_t st);
+hipError_t launch_twin_kick_drift(int n, float dt, float domain, Float4 *posm, const float *vx,
+                                  const float *vy, const float *vz, const float *ax,
+                                  const float *ay, const float *az, float *vhx, float *vhy,
+                                  float *vhz, hipStream_t st);
+hipError_t launch_vel_kick_raw(int n, float dt, float keep, const float *vhx, const float *vhy,
+                               const float *vhz, const float *ax, const float *ay, const float *az,
+                               float *vx, float *vy, float *vz, hipStream_t st);
+hipError_t launch_count_interactions(Sim *s, unsigned long long *out);
 
 }  // namespace nb
