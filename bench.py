@@ -39,14 +39,6 @@ PEAK_HBM_GBS = 8000.0              # MI355X HBM3E peak
 REFERENCE_MS_PER_STEP = 150.0      # reference README, RTX 500 Ada, 2,097,152 particles, theta=0.6
 
 
-class _DevArray:
-    """Zero-copy view of library-owned device memory for torch (CUDA array interface)."""
-
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False),
-                                         "version": 2}
-
-
 def cpu_baseline(ic, bits, steps=1):
     """The host oracle (same algorithm, same parameters) timed on this machine's cores on
     `steps` steps of the full 2,097,152-particle workload."""
@@ -122,23 +114,16 @@ def main():
     sim.set_state(ic["x"], ic["y"], ic["z"], ic["m"])
     U, M, n_oct = sim.tree_counts()
 
-    acc = None
+    stepper = None
     if world > 1:
-        g0 = rank * (ngroups // world)
-        g1 = g0 + ngroups // world
-        sim.set_traversal_range(g0, g1)
-        v = sim.device_view()
-        acc = [torch.as_tensor(_DevArray(p, n), device=f"cuda:{local_rank}") for p in (v.ax, v.ay, v.az)]
-        b0, b1 = g0 * group, min(g1 * group, n)
+        from nbody_amd import parallel
+        stepper = parallel.ShardedTraversal(parallel.GpuBackend(sim, f"cuda:{local_rank}"))
 
     def one_step():
-        sim.update()
-        if world > 1:
-            sim.sync()  # traversal done on the library's stream before RCCL reads the slices
-            for a in acc:
-                dist.all_gather_into_tensor(a, a[b0:b1])
-            torch.cuda.current_stream().synchronize()
-            sim.finish_step()
+        if stepper is None:
+            sim.update()
+        else:
+            stepper.step()
 
     def fence():
         if world > 1:

@@ -1,0 +1,155 @@
+"""world_size-2/3 gloo tests (CPU) of the multi-GPU choreography in nbody_amd/parallel.py.
+The compute is injected: here it is the host oracle, on the GPUs it is libnbody_mi355.so."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_lib as O
+from nbody_amd import parallel
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class OracleBackend:
+    """ShardedTraversal backend made of oracle stages: replicated state, sharded traversal."""
+
+    def __init__(self, ic, n, group, theta, dt, eps, bits):
+        self.n, self.group, self.theta, self.dt, self.eps, self.bits = n, group, theta, dt, eps, bits
+        b = O.full_build(ic["x"], ic["y"], ic["z"], ic["m"], 5.0, bits, 32)
+        p = b["perm"]
+        self.x, self.y, self.z, self.m = b["xs"], b["ys"], b["zs"], b["ms"]
+        self.v = [ic[k][p].copy() for k in ("vx", "vy", "vz")]
+        self.acc = [torch.zeros(n, dtype=torch.float32) for _ in range(3)]
+        self.g0, self.g1 = 0, (n + group - 1) // group
+
+    def set_traversal_range(self, g0, g1):
+        self.g0, self.g1 = g0, g1
+
+    def update(self):
+        a = [t.numpy() for t in self.acc]
+        x, y, z, vh = O.leapfrog_pos(self.dt, 5.0, self.x, self.y, self.z, *self.v, *a)
+        b = O.full_build(x, y, z, self.m, 5.0, self.bits, 32)
+        p = b["perm"]
+        self.x, self.y, self.z, self.m = b["xs"], b["ys"], b["zs"], b["ms"]
+        self.vh = [h[p] for h in vh]
+        ax, ay, az, _ = O.traverse(b["tree"], b["com"], self.x, self.y, self.z, self.m, self.group,
+                                   self.theta, self.eps, 1.0, 5.0)
+        lo, hi = self.g0 * self.group, min(self.g1 * self.group, self.n)
+        for t, full in zip(self.acc, (ax, ay, az)):
+            t.zero_()                      # only the own range is "computed" on this rank
+            t[lo:hi] = torch.from_numpy(full[lo:hi])
+
+    def wait(self):
+        pass
+
+    def acc_tensors(self):
+        return self.acc
+
+    def finish_step(self):
+        self.v = [(np.float32(0.5) * a.numpy() * np.float32(self.dt) + h).astype(np.float32)
+                  for a, h in zip(self.acc, self.vh)]
+
+
+def _ic(n):
+    import nbody_amd as nb
+    return nb.sample_ic(nb.IC_DISK, n, 7)
+
+
+def _sharded_worker(rank, world, port, n, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    be = OracleBackend(_ic(n), n, 64, 0.5, 1e-3, 0.01, 21)
+    st = parallel.ShardedTraversal(be)
+    for _ in range(3):
+        st.step()
+    if rank == 0:
+        q.put((be.x, be.v[0], be.acc[0].numpy().copy(), st.even))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 2048), (2, 1000), (3, 1500)])
+def test_sharded_traversal_equals_single_rank(world, n):
+    """even split (2048 = 2*16 groups), ragged split (1000), 3 ranks with a partial chunk."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    x, vx, ax, even = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert even == (n % (world * 64) == 0)
+    ref = OracleBackend(_ic(n), n, 64, 0.5, 1e-3, 0.01, 21)
+    for _ in range(3):
+        ref.update()
+        ref.finish_step()
+    assert np.array_equal(x, ref.x) and np.array_equal(vx, ref.v[0])
+    assert np.array_equal(ax, ref.acc[0].numpy())
+
+
+def _ring_worker(rank, world, port, n_local, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = n_local * world
+    ic = _ic(n)
+    posm = np.stack([ic["x"], ic["y"], ic["z"], ic["m"]], 1).astype(np.float32)
+    mine = torch.from_numpy(posm[rank * n_local:(rank + 1) * n_local].copy())
+    acc = [np.zeros(n_local, np.float64) for _ in range(3)]
+    seen = []
+
+    def tile_kernel(targets, sources, accumulate):
+        t, s = targets.numpy(), sources.numpy()
+        seen.append(s[0, 0].item())
+        if not accumulate:
+            for a in acc:
+                a[:] = 0
+        # forces of the tile's bodies on my bodies: float64 direct sum, targets placed first
+        both = np.concatenate([t, s])
+        r = O.direct_f64(both[:, 0], both[:, 1], both[:, 2],
+                         np.concatenate([np.zeros(len(t), np.float32), s[:, 3]]), 0.01, 1.0,
+                         0, len(t))
+        for a, d in zip(acc, r):
+            a += d
+
+    parallel.ring_direct_sum(mine, tile_kernel)
+    q.put((rank, acc[0].copy(), acc[1].copy(), seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ring_direct_sum_equals_full_sum(world):
+    n_local = 200
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ring_worker, args=(r, world, port, n_local, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n = n_local * world
+    ic = _ic(n)
+    rx, ry, _ = O.direct_f64(ic["x"], ic["y"], ic["z"], ic["m"], 0.01, 1.0)
+    for rank, ax, ay, seen in res:
+        sl = slice(rank * n_local, (rank + 1) * n_local)
+        assert np.allclose(ax, rx[sl], rtol=1e-10) and np.allclose(ay, ry[sl], rtol=1e-10)
+        # every rank saw every tile exactly once, its own first, then its left neighbours'
+        order = [(rank - k) % world for k in range(world)]
+        assert seen == [float(ic["x"][o * n_local]) for o in order]
