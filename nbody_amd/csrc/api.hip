@@ -47,12 +47,12 @@ void free_all(Sim *s)
         F(s->x[i]); F(s->y[i]); F(s->z[i]); F(s->m[i]); F(s->vhx[i]); F(s->vhy[i]); F(s->vhz[i]);
         F(s->vx[i]); F(s->vy[i]); F(s->vz[i]); F(s->id[i]); F(s->keys[i]); F(s->vals[i]);
     }
-    F(s->ax); F(s->ay); F(s->az); F(s->posm); F(s->ghist); F(s->zero_block); F(s->com_counter);
+    F(s->ax); F(s->ay); F(s->az); F(s->posm); F(s->posm2); F(s->ghist); F(s->zero_block); F(s->com_counter);
     F(s->counts); F(s->unique); F(s->first_pt); F(s->lfc); F(s->leaf_key); F(s->rt_pd);
     F(s->rt_level); F(s->rt_lb); F(s->rt_le); F(s->rt_left); F(s->rt_right); F(s->depth_key);
     F(s->bfs); F(s->octid); F(s->o_depth); F(s->o_first_child); F(s->o_num_children); F(s->o_lb);
     F(s->o_le); F(s->o_level); F(s->o_pb); F(s->o_pe); F(s->o_parent); F(s->o_size); F(s->o_wsum);
-    F(s->nodeA); F(s->nodeB); F(s->list_len); F(s->inter_dev);
+    F(s->nodeA); F(s->nodeB); F(s->list_len); F(s->inter_dev); F(s->trav_tail);
     F(s->tw_posm); F(s->tw_pot); F(s->ds_pot);
     for (int k = 0; k < 3; ++k) { F(s->tw_v[k]); F(s->tw_vh[k]); F(s->tw_a[k]); F(s->ds_a[k]); }
     if (s->counts_host) (void) hipHostFree(s->counts_host);
@@ -82,6 +82,8 @@ int alloc_all(Sim *s)
     }
     NB_HIP(s, dalloc(&s->ax, n)); NB_HIP(s, dalloc(&s->ay, n)); NB_HIP(s, dalloc(&s->az, n));
     NB_HIP(s, dalloc(&s->posm, n));
+    NB_HIP(s, dalloc(&s->posm2, 8 * ((n + 1) / 2)));
+    NB_HIP(s, hipMemsetAsync(s->posm2, 0, 8 * ((n + 1) / 2) * 4, s->stream));
 
     // sort scratch: ghist[8*256] | tickets[16] | status[P][tiles][256]
     s->sort_tiles = (int) ((n + SORT_TILE - 1) / SORT_TILE);
@@ -125,6 +127,18 @@ int alloc_all(Sim *s)
     const size_t ngroups = (n + s->group - 1) / s->group;
     NB_HIP(s, dalloc(&s->list_len, ngroups));
     NB_HIP(s, hipMemsetAsync(s->list_len, 0, std::max<size_t>(ngroups, 1) * 4, s->stream));
+    {
+        TravTail t{};
+        t.ax = s->ax; t.ay = s->ay; t.az = s->az;
+        t.list_len = s->list_len;
+        t.err = &s->counts->err;
+        for (int i = 0; i < 2; ++i) {
+            t.vhx[i] = s->vhx[i]; t.vhy[i] = s->vhy[i]; t.vhz[i] = s->vhz[i];
+            t.vx[i] = s->vx[i]; t.vy[i] = s->vy[i]; t.vz[i] = s->vz[i];
+        }
+        NB_HIP(s, dalloc(&s->trav_tail, 1));
+        NB_HIP(s, hipMemcpy(s->trav_tail, &t, sizeof t, hipMemcpyHostToDevice));
+    }
     NB_HIP(s, dalloc(&s->inter_dev, (size_t) TIMING_RING));
     NB_HIP(s, hipMemsetAsync(s->inter_dev, 0, TIMING_RING * 8, s->stream));
     if (s->p.num_steps_validator > 0) {

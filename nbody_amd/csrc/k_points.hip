@@ -118,7 +118,8 @@ __global__ __launch_bounds__(256) void k_permute(
     const uint32_t *__restrict__ idi, float *__restrict__ xo, float *__restrict__ yo,
     float *__restrict__ zo, float *__restrict__ mo, float *__restrict__ hxo,
     float *__restrict__ hyo, float *__restrict__ hzo, uint32_t *__restrict__ ido,
-    Float4 *__restrict__ posm, const float *__restrict__ vxi, const float *__restrict__ vyi,
+    Float4 *__restrict__ posm, float *__restrict__ posm2, const float *__restrict__ vxi,
+    const float *__restrict__ vyi,
     const float *__restrict__ vzi, float *__restrict__ vxo, float *__restrict__ vyo,
     float *__restrict__ vzo)
 {
@@ -130,6 +131,8 @@ __global__ __launch_bounds__(256) void k_permute(
     hxo[i] = hxi[s]; hyo[i] = hyi[s]; hzo[i] = hzi[s];
     ido[i] = idi[s];
     posm[i] = Float4{px, py, pz, pm};
+    float *pr = posm2 + 8 * (i >> 1) + (i & 1);   // pair record (x0,x1,y0,y1,z0,z1,m0,m1)
+    pr[0] = px; pr[2] = py; pr[4] = pz; pr[6] = pm;
     if (ALL) {
         vxo[i] = vxi[s]; vyo[i] = vyi[s]; vzo[i] = vzi[s];
     }
@@ -236,13 +239,13 @@ hipError_t launch_permute(Sim *s, bool all_fields)
         hipLaunchKernelGGL(k_permute<true>, dim3(nblk(s->n, 256)), dim3(256), 0, s->stream, s->n,
                            perm, s->x[c], s->y[c], s->z[c], s->m[c], s->vhx[c], s->vhy[c],
                            s->vhz[c], s->id[c], s->x[o], s->y[o], s->z[o], s->m[o], s->vhx[o],
-                           s->vhy[o], s->vhz[o], s->id[o], s->posm, s->vx[c], s->vy[c], s->vz[c],
+                           s->vhy[o], s->vhz[o], s->id[o], s->posm, s->posm2, s->vx[c], s->vy[c], s->vz[c],
                            s->vx[o], s->vy[o], s->vz[o]);
     else
         hipLaunchKernelGGL(k_permute<false>, dim3(nblk(s->n, 256)), dim3(256), 0, s->stream, s->n,
                            perm, s->x[c], s->y[c], s->z[c], s->m[c], s->vhx[c], s->vhy[c],
                            s->vhz[c], s->id[c], s->x[o], s->y[o], s->z[o], s->m[o], s->vhx[o],
-                           s->vhy[o], s->vhz[o], s->id[o], s->posm, nullptr, nullptr, nullptr,
+                           s->vhy[o], s->vhz[o], s->id[o], s->posm, s->posm2, nullptr, nullptr, nullptr,
                            nullptr, nullptr, nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -18,10 +18,13 @@
 //   * Accepted (com, mass) records go to an LDS source list.  Children of opened nodes are
 //     split by the parent's child-leaf mask: inner children return to the node stack, leaf
 //     children go to a separate LDS leaf stack and never pay for a distance test.
-//   * Leaves are expanded 64 at a time: a wave scan of their particle counts, then every
-//     lane locates "its" particle of the concatenated ranges by a 6-step search, so each
-//     global load instruction brings in 64 particles; the next chunk's load is issued
-//     before the current chunk's forces are evaluated.
+//   * Leaves are taken 64 at a time in memory order; leaves that are adjacent in the sorted
+//     particle array (siblings always are) fuse into runs.  A run is consumed straight from
+//     the pair-interleaved particle array through the SCALAR data path: the run bounds are
+//     wave-uniform, so each (x0,x1,y0,y1,z0,z1,m0,m1) record is one s_load_dwordx8 into
+//     SGPRs that feed the packed force instructions directly -- no LDS staging, no vector
+//     address arithmetic, the next record is requested before the current one is evaluated.
+//     Only the odd particle at either end of a run goes through the LDS list.
 //   * Whenever the source list holds >= 64 entries each lane (= one body) runs the force
 //     loop over 32 broadcast entry PAIRS: v_pk_{add,mul,fma}_f32 evaluate two sources per
 //     instruction, v_rsq_f32 once per source.
@@ -34,6 +37,8 @@ namespace nb {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v8f __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int TRAV_RESERVE = 7 * 24;  // single-pop fallback never needs more than 7/level
 
@@ -59,18 +64,13 @@ struct alignas(16) WaveLds {
     v4f lzm[64];
     int stack[TRAV_STACK];
     int leaf[TRAV_LEAF_STACK];
-    int lpre[64];
-    int lpb[64];
 };
 
 template <int G, bool FUSE_VEL, bool WALK_ONLY>
-__global__ __launch_bounds__(64 * TRAV_WAVES) void k_traverse(
-    int n, int g0, int g1, const Float4 *__restrict__ posm, const Float4 *__restrict__ nodeA,
-    const NodeB *__restrict__ nodeB, float theta, float eps2, float gravity, float domain,
-    float *__restrict__ ax, float *__restrict__ ay, float *__restrict__ az,
-    uint32_t *__restrict__ list_len, float dt, float keep, const float *__restrict__ vhx,
-    const float *__restrict__ vhy, const float *__restrict__ vhz, float *__restrict__ vx,
-    float *__restrict__ vy, float *__restrict__ vz, uint32_t *err)
+__global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
+    int n, int g0, int g1, const Float4 *__restrict__ posm, const v8f *__restrict__ posm2,
+    const Float4 *__restrict__ nodeA, const NodeB *__restrict__ nodeB, float theta, float eps2,
+    float gravity, float domain, float dt, float keep, const TravTail *__restrict__ tail, int cur)
 {
     __shared__ WaveLds lds[TRAV_WAVES];
 
@@ -141,42 +141,79 @@ __global__ __launch_bounds__(64 * TRAV_WAVES) void k_traverse(
         __builtin_amdgcn_wave_barrier();
     };
 
-    // Expand up to 64 leaves from the leaf stack into the source ring.
+    // Sources of one pair record held in SGPRs (wave-uniform): no LDS, no VGPR staging.
+    auto pair_force_s = [&](const v8f r) {
+        if (WALK_ONLY) { fx2 += v2f{r[0], r[1]}; return; }
+        const v2f dx = v2f{r[0], r[1]} - px2, dy = v2f{r[2], r[3]} - py2, dz = v2f{r[4], r[5]} - pz2;
+        const v2f s = __builtin_elementwise_fma(
+            dz, dz, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dx, dx, e2)));
+        const v2f s3 = s * s * s;
+        v2f inv = {__builtin_amdgcn_rsqf(s3.x), __builtin_amdgcn_rsqf(s3.y)};
+        inv *= v2f{r[6], r[7]};
+        fx2 = __builtin_elementwise_fma(dx, inv, fx2);
+        fy2 = __builtin_elementwise_fma(dy, inv, fy2);
+        fz2 = __builtin_elementwise_fma(dz, inv, fz2);
+    };
+    // Append the particles selected by `want` (one per lane, index idx) to the source ring.
+    auto append_particles = [&](bool want, int idx) {
+        const unsigned long long wm = __ballot(want);
+        if (wm == 0ull) return;
+        if (want) write_entry((head + list_n + mbcnt(wm)) & 127, posm[idx]);
+        list_n += (int) __popcll(wm);
+        if (list_n >= 64) flush64();
+    };
+
+    // Take up to 64 leaves (memory order) from the leaf stack and evaluate their particles.
     auto process_leaves = [&]() {
         const int cnt = min(64, leaf_n);
         const bool valid = lane < cnt;
-        const int id = valid ? L.leaf[leaf_n - 1 - lane] : 0;
+        const int id = valid ? L.leaf[leaf_n - cnt + lane] : 0;
         leaf_n -= cnt;
         const NodeB Bl = nodeB[id];
-        const uint32_t np = valid ? (uint32_t) Bl.count : 0u;
-        const uint32_t inc = wave_incl_scan_u32(np);
-        const int P = (int) __shfl(inc, 63, 64);
-        L.lpre[lane] = (int) (inc - np);
-        L.lpb[lane] = Bl.first;
-        total += (uint32_t) P;
-        __builtin_amdgcn_wave_barrier();
-        auto fetch = [&](int c0) -> Float4 {
-            const int idx = c0 + lane;
-            Float4 v = Float4{0.f, 0.f, 0.f, 0.f};
-            if (idx < P) {
-                int j = 0;
-#pragma unroll
-                for (int step = 32; step >= 1; step >>= 1)
-                    if (L.lpre[j + step] <= idx) j += step;
-                v = posm[L.lpb[j] + (idx - L.lpre[j])];
+        const int pb = Bl.first;
+        const int pe = pb + Bl.count;                    // exclusive end
+        const int prev_end = __shfl_up(pe, 1, 64);
+        const int next_pb = __shfl_down(pb, 1, 64);
+        const bool is_head = valid && (lane == 0 || prev_end != pb);
+        const bool is_tail = valid && (lane == cnt - 1 || next_pb != pe);
+        // odd particle at either end of a run -> LDS list (two batched gathers per 64 leaves)
+        append_particles(is_head && (pb & 1), pb);
+        append_particles(is_tail && (pe & 1), pe - 1);
+        // whole pairs of every run -> scalar path
+        unsigned long long hm = __ballot(is_head);
+        while (hm) {
+            const int h = (int) __builtin_ctzll(hm);
+            hm &= hm - 1;
+            const int t = (hm ? (int) __builtin_ctzll(hm) : cnt) - 1;   // last lane of the run
+            const int rb = __builtin_amdgcn_readlane(pb, h);
+            const int re = __builtin_amdgcn_readlane(pe, t);
+            total += (uint32_t) (re - rb);
+            int q0 = (rb + 1) >> 1;
+            const int q1 = re >> 1;                                     // pairs [q0, q1)
+            if (q0 < q1 && (q0 & 1)) pair_force_s(posm2[q0++]);         // align to 64 B
+            if (q0 + 1 < q1) {   // two pairs (one 64-byte record) per scalar load, one load ahead;
+                                 // two register sets used alternately so nothing is copied
+                const v16f *P16 = reinterpret_cast<const v16f *>(posm2);
+                const int d1 = q1 >> 1;
+                int d = q0 >> 1;
+                v16f ra = P16[d], rb2;
+                while (true) {
+                    const bool hb = d + 1 < d1;
+                    if (hb) rb2 = P16[d + 1];
+                    pair_force_s(ra.lo);
+                    pair_force_s(ra.hi);
+                    if (!hb) break;
+                    const bool ha = d + 2 < d1;
+                    if (ha) ra = P16[d + 2];
+                    pair_force_s(rb2.lo);
+                    pair_force_s(rb2.hi);
+                    if (!ha) break;
+                    d += 2;
+                }
+                q0 = d1 << 1;
             }
-            return v;
-        };
-        Float4 nxt = fetch(0);
-        for (int c0 = 0; c0 < P; c0 += 64) {
-            const Float4 cur = nxt;
-            if (c0 + 64 < P) nxt = fetch(c0 + 64);
-            const int c = min(64, P - c0);
-            if (lane < c) write_entry((head + list_n + lane) & 127, cur);
-            list_n += c;
-            if (list_n >= 64) flush64();
+            if (q0 < q1) pair_force_s(posm2[q0]);
         }
-        __builtin_amdgcn_wave_barrier();
     };
 
     while (true) {
@@ -186,7 +223,7 @@ __global__ __launch_bounds__(64 * TRAV_WAVES) void k_traverse(
         const int room = TRAV_STACK - TRAV_RESERVE - sp;
         const int k = min(min(sp, 64), max(room / 7, 1));
         const bool valid = lane < k;
-        const int node = valid ? L.stack[sp - 1 - lane] : 0;
+        const int node = valid ? L.stack[sp - k + lane] : 0;
         sp -= k;
         const Float4 A = nodeA[node];
         const NodeB B = nodeB[node];
@@ -194,7 +231,7 @@ __global__ __launch_bounds__(64 * TRAV_WAVES) void k_traverse(
         // d2min over the group's bodies, two per packed instruction
         const v2f ax2 = {A.x, A.x}, ay2 = {A.y, A.y}, az2 = {A.z, A.z};
         float dmin = dinit;
-#pragma unroll 8
+#pragma unroll 4
         for (int j = 0; j < G / 2; ++j) {
             const v4f q = L.bxy[j];
             const v2f qz = L.bz[j];
@@ -223,7 +260,7 @@ __global__ __launch_bounds__(64 * TRAV_WAVES) void k_traverse(
         const uint32_t exc = inc - packed;
         const int tot_i = (int) (tot & 0xffffu), tot_l = (int) (tot >> 16);
         if (sp + tot_i > TRAV_STACK || leaf_n + tot_l > TRAV_LEAF_STACK) {
-            if (lane == 0) atomicOr(err, (uint32_t) DEV_ERR_STACK);  // unreachable by construction
+            if (lane == 0) atomicOr(tail->err, (uint32_t) DEV_ERR_STACK);  // unreachable by construction
             break;
         }
         int di = sp + (int) (exc & 0xffffu), dl = leaf_n + (int) (exc >> 16);
@@ -250,14 +287,14 @@ __global__ __launch_bounds__(64 * TRAV_WAVES) void k_traverse(
     }
     const float fx = fx2.x + fx2.y, fy = fy2.x + fy2.y, fz = fz2.x + fz2.y;
 
-    if (lane == 0) list_len[g] = total;
+    if (lane == 0) tail->list_len[g] = total;
     if (active) {
         const float axv = gravity * fx, ayv = gravity * fy, azv = gravity * fz;
-        ax[b] = axv; ay[b] = ayv; az[b] = azv;
+        tail->ax[b] = axv; tail->ay[b] = ayv; tail->az[b] = azv;
         if (FUSE_VEL) {
-            vx[b] = fmaf(0.5f * axv, dt, vhx[b]) * keep;
-            vy[b] = fmaf(0.5f * ayv, dt, vhy[b]) * keep;
-            vz[b] = fmaf(0.5f * azv, dt, vhz[b]) * keep;
+            tail->vx[cur][b] = fmaf(0.5f * axv, dt, tail->vhx[cur][b]) * keep;
+            tail->vy[cur][b] = fmaf(0.5f * ayv, dt, tail->vhy[cur][b]) * keep;
+            tail->vz[cur][b] = fmaf(0.5f * azv, dt, tail->vhz[cur][b]) * keep;
         }
     }
 }
@@ -344,12 +381,11 @@ hipError_t launch_traverse(Sim *s, bool fuse_vel)
         const int grid = (g1 - g0 + TRAV_WAVES - 1) / TRAV_WAVES;
         const float eps2 = s->p.softening_factor * s->p.softening_factor;
         const float keep = 1.0f - s->p.velocity_dampening;
-#define NB_TRAV(GG, FV, WO)                                                                        \
+#define NB_TRAV(GG, FV, WO)                                                                      \
     hipLaunchKernelGGL((k_traverse<GG, FV, WO>), dim3(grid), dim3(64 * TRAV_WAVES), 0, s->stream,    \
-                       s->n, g0, g1, s->posm, s->nodeA, s->nodeB, s->p.theta, eps2,              \
-                       s->p.gravity, s->p.domain_size, s->ax, s->ay, s->az, s->list_len,         \
-                       s->p.dt, keep, s->vhx[c], s->vhy[c], s->vhz[c], s->vx[c], s->vy[c],       \
-                       s->vz[c], &s->counts->err)
+                       s->n, g0, g1, s->posm, (const v8f *) s->posm2, s->nodeA, s->nodeB,            \
+                       s->p.theta, eps2, s->p.gravity, s->p.domain_size, s->p.dt, keep,              \
+                       s->trav_tail, c)
         const bool walk_only = (s->p.flags & NBODY_FLAG_DEBUG_WALK_ONLY) != 0;
         if (walk_only) {
             if (s->group == 64) NB_TRAV(64, false, true); else NB_TRAV(32, false, true);

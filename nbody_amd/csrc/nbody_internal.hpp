@@ -29,6 +29,17 @@ struct Float4 { float x, y, z, w; };
 struct NodeB { float size; int32_t first; int32_t count; uint32_t meta; };
 constexpr uint32_t NODE_LEAF = 0x80000000u;
 
+// Output pointers of the traversal kernel, kept in device memory and read once at the end
+// of the kernel so that they do not occupy scalar registers during the walk.  Velocity
+// buffers come in pairs; the kernel indexes them with the handle's `cur`.
+struct TravTail {
+    float *ax, *ay, *az;
+    uint32_t *list_len;
+    uint32_t *err;
+    float *vhx[2], *vhy[2], *vhz[2];
+    float *vx[2], *vy[2], *vz[2];
+};
+
 // Device-resident counters written by the build kernels (one int each).
 struct Counts {
     int32_t U;       // unique codes
@@ -55,7 +66,8 @@ struct Sim {
     float *vx[2]{}, *vy[2]{}, *vz[2]{};
     uint32_t *id[2]{};
     float *ax = nullptr, *ay = nullptr, *az = nullptr;
-    Float4 *posm = nullptr;       // (x,y,z,m) in sorted order, read by the traversal
+    Float4 *posm = nullptr;       // (x,y,z,m) in sorted order
+    float *posm2 = nullptr;       // same, pair-interleaved: (x0,x1,y0,y1,z0,z1,m0,m1) per pair
     int cur = 0;                  // which buffer of each pair is current
 
     // sort
@@ -101,6 +113,7 @@ struct Sim {
     Float4 *nodeA = nullptr;      // (comx, comy, comz, mass)
     NodeB *nodeB = nullptr;
     uint32_t *list_len = nullptr; // [ceil(n/group)]
+    TravTail *trav_tail = nullptr;
 
     // sharded traversal
     int trav_g0 = 0, trav_g1 = -1;
