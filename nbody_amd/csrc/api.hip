@@ -93,7 +93,7 @@ int alloc_all(Sim *s)
 
     // build scratch zeroed once per build: tickets[16] | scan_status[2][T] | dhist[256] |
     // rank_status[R][256]
-    s->max_scan_tiles = (int) ((n + SCAN_TILE - 1) / SCAN_TILE);
+    s->max_scan_tiles = (int) ((n + 1023) / 1024);  // smallest compaction tile is 1024
     s->rank_tiles = (int) ((2 * n + SORT_TILE - 1) / SORT_TILE);
     const size_t zwords = 16 + 2 * (size_t) s->max_scan_tiles + 256 + (size_t) s->rank_tiles * 256;
     s->zero_bytes = (zwords * 4 + 15) / 16 * 16;

@@ -135,8 +135,9 @@ __device__ __forceinline__ uint32_t lb_exclusive_wave(uint32_t *status, int tile
     return excl;
 }
 
-// Serial look-back by a single thread for one quantity out of `stride` per tile
-// (used by the radix pass: thread d follows digit d).
+// Look-back by a single thread for one quantity out of `stride` per tile (used by the radix
+// pass: thread d follows digit d).  The words of the 8 nearest unread predecessors are
+// requested together, so the walk costs one memory round trip per 8 tiles, not per tile.
 __device__ __forceinline__ uint32_t lb_exclusive_thread(uint32_t *status, int stride, int q,
                                                         int tile, uint32_t aggregate,
                                                         uint32_t *err)
@@ -147,10 +148,22 @@ __device__ __forceinline__ uint32_t lb_exclusive_thread(uint32_t *status, int st
     }
     lb_store(&status[(size_t) tile * stride + q], LB_AGG | aggregate);
     uint32_t excl = 0;
-    for (int t = tile - 1; t >= 0; --t) {
-        const uint32_t w = lb_wait(&status[(size_t) t * stride + q], err);
-        excl += w & LB_MASK;
-        if ((w >> 30) == 2u) break;
+    int t = tile - 1;
+    bool done = false;
+    while (!done && t >= 0) {
+        uint32_t w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            w[i] = (t - i >= 0) ? lb_load(&status[(size_t) (t - i) * stride + q]) : LB_PREFIX;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (done) break;
+            uint32_t v = w[i];
+            if ((v >> 30) == 0u) v = lb_wait(&status[(size_t) (t - i) * stride + q], err);
+            excl += v & LB_MASK;
+            done = (v >> 30) == 2u;
+        }
+        t -= 8;
     }
     lb_store(&status[(size_t) tile * stride + q], LB_PREFIX | (excl + aggregate));
     return excl;

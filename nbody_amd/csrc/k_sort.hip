@@ -162,7 +162,7 @@ static hipError_t sort_impl(Sim *s)
     // layout of the zeroed block: ghist[8*256] | tickets[8] (+pad to 16) | status[P][tiles][256]
     uint32_t *tickets = s->ghist + 8 * 256;
     uint32_t *status = tickets + 16;
-    const int hgrid = std::min(tiles, 1024);
+    const int hgrid = std::min(tiles, 256);  // few blocks: the hot bins take one atomic per block
     hipLaunchKernelGGL((k_sort_hist<KeyT, NPASS>), dim3(hgrid), dim3(256), 0, s->stream,
                        (const KeyT *) s->keys[0], n, s->ghist);
     int in = 0;

@@ -221,7 +221,8 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
         if (sp == 0) break;
 
         const int room = TRAV_STACK - TRAV_RESERVE - sp;
-        const int k = min(min(sp, 64), max(room / 7, 1));
+        // leaf_n < 64 here; every popped node may add up to 8 leaves
+        const int k = min(min(min(sp, 64), max(room / 7, 1)), (TRAV_LEAF_STACK - leaf_n) >> 3);
         const bool valid = lane < k;
         const int node = valid ? L.stack[sp - k + lane] : 0;
         sp -= k;

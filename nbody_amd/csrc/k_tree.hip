@@ -101,8 +101,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_unique(const KeyT *__restrict_
 // Leaf coarsening + compaction.  A leaf is the largest octree cell around a code that
 // holds at most max_codes unique codes (never larger than the cell in which the code is
 // alone with respect to its neighbours); a code is kept iff it is the first code of its
-// leaf.  Equivalent to the reference's climb (merge_leaves) but each level is resolved by
-// two bounded binary searches on key prefixes: counts above max_codes+1 are never needed.
+// leaf.  The reference finds a code's leaf by climbing level by level (merge_leaves);
+// the same flag follows from ONE cell: let C be the deepest cell that code i shares with
+// its predecessor (level lcp(i, i-1) / 3).  Cell populations only grow towards the root,
+// so i's leaf lies strictly below C -- and then starts at i -- exactly when C holds more
+// than max_codes codes; otherwise the leaf is C or an ancestor and i is not its first
+// code.  C's population is only needed up to max_codes + 1: find C's first code with a
+// bounded binary search to the left, then test the code max_codes places after it.
 // Outputs lfc[0..M) (index of each leaf's first code), lfc[M] = U (the sentinel the
 // reference gets from cub::DevicePartition's reversed rear), leaf_key[0..M), M, n_bt.
 // ---------------------------------------------------------------------------
@@ -111,32 +116,23 @@ __device__ __forceinline__ bool leaf_head_flag(const KeyT *__restrict__ u, int i
                                                int max_codes)
 {
     constexpr int KB = KeyBits<KeyT>::KB;
+    if (i == 0) return true;
     const KeyT c = u[i];
-    const int l1 = i > 0 ? lcp_keys(c, u[i - 1]) : -3;
-    const int l2 = i < U - 1 ? lcp_keys(c, u[i + 1]) : -3;
-    const int ld = max(l1 / 3, l2 / 3) + 1;  // C division: -3/3 = -1
-    const int lcap = min(i, max_codes + 1);
-    const int rcap = min(U - 1 - i, max_codes + 1);
-    int left_acc = 0;
-    for (int t = ld - 1; t >= 0; --t) {
-        const int sh = KB - 3 * t;
-        const KeyT pre = c >> sh;
-        int lo = 0, hi = lcap;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if ((u[i - mid] >> sh) == pre) lo = mid; else hi = mid - 1;
-        }
-        const int left = lo;
-        lo = 0; hi = rcap;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if ((u[i + mid] >> sh) == pre) lo = mid; else hi = mid - 1;
-        }
-        if (left + lo + 1 > max_codes) break;
-        left_acc = left;
+    const int level = lcp_keys(c, u[i - 1]) / 3;
+    const int sh = KB - 3 * level;
+    const KeyT pre = c >> sh;
+    // first code of C is i - left, left in [1, max_codes]; beyond that C is too full anyway
+    int lo = 1, hi = min(i, max_codes);
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((u[i - mid] >> sh) == pre) lo = mid; else hi = mid - 1;
     }
-    return left_acc == 0;
+    const int probe = i - lo + max_codes;  // the (max_codes+1)-th code counted from C's start
+    return probe < U && (u[probe] >> sh) == pre;
 }
+
+constexpr int LEAF_ITEMS = 4;
+constexpr int LEAF_TILE = SCAN_THREADS * LEAF_ITEMS;
 
 template <typename KeyT>
 __global__ __launch_bounds__(SCAN_THREADS) void k_leaves(const KeyT *__restrict__ unique,
@@ -153,15 +149,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_leaves(const KeyT *__restrict_
     if (tid == 0) s_bcast[0] = atomicAdd(ticket, 1u);
     __syncthreads();
     const int tile = (int) s_bcast[0];
-    const int ntiles = (U + SCAN_TILE - 1) / SCAN_TILE;
+    const int ntiles = (U + LEAF_TILE - 1) / LEAF_TILE;
     if (tile >= ntiles) return;
-    const int base = tile * SCAN_TILE + tid * SCAN_ITEMS;
+    const int base = tile * LEAF_TILE + tid * LEAF_ITEMS;
     const bool single = U <= max_codes;  // whole set fits one leaf (undefined in the reference)
 
-    bool f[SCAN_ITEMS];
+    bool f[LEAF_ITEMS];
     uint32_t cnt = 0;
 #pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; ++j) {
+    for (int j = 0; j < LEAF_ITEMS; ++j) {
         const int i = base + j;
         f[j] = false;
         if (i < U) f[j] = single ? (i == 0) : leaf_head_flag<KeyT>(unique, i, U, max_codes);
@@ -177,7 +173,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_leaves(const KeyT *__restrict_
     const uint32_t tile_excl = s_bcast[1];
     uint32_t pos = tile_excl + excl;
 #pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; ++j) {
+    for (int j = 0; j < LEAF_ITEMS; ++j) {
         if (f[j]) {
             lfc[pos] = base + j;
             leaf_key[pos] = unique[base + j];
@@ -450,7 +446,8 @@ static hipError_t build_impl(Sim *s)
     hipLaunchKernelGGL(k_unique<KeyT>, dim3(scan_grid), dim3(SCAN_THREADS), 0, st, sorted, n,
                        (KeyT *) s->unique, s->first_pt, s->counts, s->scan_status,
                        s->tickets + 0);
-    hipLaunchKernelGGL(k_leaves<KeyT>, dim3(scan_grid), dim3(SCAN_THREADS), 0, st,
+    const int leaf_grid = (n + LEAF_TILE - 1) / LEAF_TILE;
+    hipLaunchKernelGGL(k_leaves<KeyT>, dim3(leaf_grid), dim3(SCAN_THREADS), 0, st,
                        (const KeyT *) s->unique, s->p.max_num_codes_per_leaf, s->lfc,
                        (KeyT *) s->leaf_key, s->counts, s->scan_status + s->max_scan_tiles,
                        s->tickets + 1);

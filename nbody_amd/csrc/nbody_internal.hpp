@@ -11,10 +11,10 @@ namespace nb {
 
 // Work distribution constants shared by host sizing code and kernels.
 constexpr int SORT_THREADS = 256;
-constexpr int SORT_ITEMS = 8;                       // keys per thread per radix tile
+constexpr int SORT_ITEMS = 16;                      // keys per thread per radix tile
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;
 constexpr int SCAN_THREADS = 256;
-constexpr int SCAN_ITEMS = 4;                       // elements per thread in compaction tiles
+constexpr int SCAN_ITEMS = 16;                      // elements per thread in compaction tiles
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 constexpr int TRAV_WAVES = 4;                       // groups (waves) per traversal workgroup
 constexpr int TRAV_STACK = 512;                     // LDS inner-node stack entries per wave
