@@ -72,7 +72,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--morton-bits", type=int, default=int(os.environ.get("NBODY_MORTON_BITS", "10")))
+    ap.add_argument("--morton-bits", type=int, default=int(os.environ.get("NBODY_MORTON_BITS", "21")),
+                    help="bits per axis of the Morton key: 21 = the reference's 63-bit keys "
+                         "(default), 10 = 30-bit keys")
+    ap.add_argument("--no-alt-bits", action="store_true",
+                    help="skip the short extra run with the other key width")
     ap.add_argument("--particles-per-gpu", type=int, default=N_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--walk-only", action="store_true",
@@ -165,6 +169,32 @@ def main():
     ok = bool(np.isfinite(st["ax"]).all() and np.isfinite(st["x"]).all())
     sim.close()
 
+    alt = None
+    if world == 1 and not args.no_alt_bits and not args.walk_only:
+        # the other key width on the same particles, for the record (not part of `value`)
+        alt_bits = 10 if args.morton_bits == 21 else 21
+        p2 = nb.Params(**{**params.__dict__, "morton_bits": alt_bits})
+        with nb.Simulation(p2) as s2:
+            s2.set_state(ic["x"], ic["y"], ic["z"], ic["m"])
+            s2.step(3)
+            s2.get_timings()
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            s2.step(20)
+            s2.sync()
+            tb = time.perf_counter()
+            t2 = s2.get_timings()
+        alt = {"morton_bits": alt_bits, "ms_per_step": round((tb - ta) * 1e3 / 20, 4),
+               "traversal_ms": round(t2["ms_traverse"] / 20, 4),
+               "build_ms": round((t2["ms_integrate"] + t2["ms_sort"] + t2["ms_build"] + t2["ms_com"]) / 20, 4),
+               "interactions_per_step": round(t2["interactions"] / 20)}
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
+            traffic = json.load(f)["k_traverse"]["bytes"]
+    except Exception:
+        pass
+
     if rank == 0:
         K = max(args.steps, 1)
         ms_step = elapsed * 1e3 / K
@@ -205,13 +235,17 @@ def main():
                              "laptop GPU; different hardware)",
             "roofline": {"bound": "valu", "kernel": "k_traverse", "achieved": round(tflops, 2),
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(tflops / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                         "frac": round(tflops / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
+                         "traffic_note": "HBM bytes per launch from the committed rocprofv3 PMC "
+                                         "passes (profiles/r1_traffic.json), not measured in this run",
                          "note": "20 FLOP x exact interaction count / mean kernel time (HIP "
                                  "events on the library stream); FP32 vector peak, MFMA unused"},
             "roofline_build": {"bound": "hbm", "achieved": round(build_gbs, 1), "peak": PEAK_HBM_GBS,
                                "unit": "GB/s", "frac": round(build_gbs / PEAK_HBM_GBS, 4),
                                "note": "300 algorithmic B/particle over integrate+sort+build+COM"},
         }
+        if alt is not None:
+            out["other_key_width"] = alt
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ic, args.morton_bits)
         print(json.dumps(out))
