@@ -67,8 +67,67 @@ def cpu_baseline(ic, bits, steps=1):
             "interactions_per_s": round(inter / (tt / steps / 1e3)) if tt > 0 else None}
 
 
+def run_direct(args, world, rank, local_rank):
+    """BASELINE.json configs[2]: O(N^2) direct sum of 1,048,576 bodies, bodies block-partitioned
+    over the ranks, (x,y,z,m) tiles passed round a ring (nbody_amd.parallel.ring_direct_sum)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import nbody_amd as nb
+    from nbody_amd import parallel
+    n = 1_048_576
+    eps, grav = 0.01, 1.0
+    n_local = n // world
+    ic = nb.sample_ic(nb.IC_SPHERE, n, 42)
+    posm = np.stack([ic["x"], ic["y"], ic["z"], np.full(n, 1.0 / n, np.float32)], 1).astype(np.float32)
+    dev = f"cuda:{local_rank}"
+    mine = torch.from_numpy(posm[rank * n_local:(rank + 1) * n_local].copy()).to(dev)
+    out = [torch.zeros(n_local, dtype=torch.float32, device=dev) for _ in range(3)]
+    lib = nb.load_library()
+    kern = parallel.gpu_tile_kernel(lib, *out, eps, grav)
+    if world == 1:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev),
+                                init_method=f"tcp://127.0.0.1:{29500 + os.getpid() % 1000}")
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        parallel.ring_direct_sum(mine, kern)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        parallel.ring_direct_sum(mine, kern)
+    fence()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    finite = bool(torch.isfinite(out[0]).all().item())
+    if rank == 0:
+        K = max(args.steps, 1)
+        rate = float(n) * n * K / elapsed
+        tf = 20 * rate / 1e12
+        print(json.dumps({
+            "metric": "interactions/s, O(N^2) direct sum", "value": round(rate), "unit": "interactions/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed * 1e3 / K, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "direct sum, 1,048,576-body uniform sphere r=0.5, m=1/N, eps=0.01",
+                       "parallelism": "single" if world == 1 else f"ring of {world} position tiles"},
+            "finite": finite,
+            "roofline": {"bound": "valu", "kernel": "k_direct", "achieved": round(tf, 2),
+                         "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_TFLOPS, 4),
+                         "traffic": None, "note": "20 FLOP x N^2 / wall time incl. ring exchange"}}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", choices=["bh", "direct"], default="bh",
+                    help="bh = the headline Barnes-Hut step (default); direct = O(N^2) direct sum")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
@@ -104,6 +163,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    if args.workload == "direct":
+        run_direct(args, world, rank, local_rank)
+        return
 
     n = args.particles_per_gpu * world
     group = 64

@@ -732,7 +732,8 @@ int nbody_direct_sum_dev(const float *targets_posm, int32_t nt, const float *sou
                          int32_t ns, float softening_factor, float gravity, float *ax, float *ay,
                          float *az, int32_t accumulate, void *stream)
 {
-    if (!targets_posm || !sources_posm || !ax || !ay || !az || nt < 0 || ns < 0)
+    if (!targets_posm || !sources_posm || !ax || !ay || !az || nt < 0 || ns < 0 ||
+        !(softening_factor > 0.0f))
         return NBODY_ERR_INVALID;
     hipError_t e = launch_direct(reinterpret_cast<const Float4 *>(targets_posm), nt,
                                  reinterpret_cast<const Float4 *>(sources_posm), ns,

@@ -42,19 +42,6 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int TRAV_RESERVE = 7 * 24;  // single-pop fallback never needs more than 7/level
 
-__device__ __forceinline__ void interact(const Float4 s, float px, float py, float pz,
-                                         float eps2, float &fx, float &fy, float &fz)
-{
-    const float dx = s.x - px, dy = s.y - py, dz = s.z - pz;
-    const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-    const float t = d2 + eps2;
-    float inv = __builtin_amdgcn_rsqf(t * t * t);
-    inv *= s.w;
-    fx = fmaf(dx, inv, fx);
-    fy = fmaf(dy, inv, fy);
-    fz = fmaf(dz, inv, fz);
-}
-
 // Per-wave LDS working set (7936 B).  Bodies and sources are stored as PAIRS,
 // (x0,x1,y0,y1) and (z0,z1[,m0,m1]), so that one 64-bit register pair feeds one packed op.
 struct alignas(16) WaveLds {
@@ -334,33 +321,60 @@ __global__ __launch_bounds__(256) void k_direct(const Float4 *__restrict__ targe
                                                 int accumulate, float *__restrict__ pot,
                                                 int self_pairs)
 {
-    __shared__ Float4 s_src[256];
+    // sources staged 256 at a time in the pair layout (x0,x1,y0,y1 | z0,z1,m0,m1)
+    __shared__ v4f s_xy[128];
+    __shared__ v4f s_zm[128];
+    float *xyf = reinterpret_cast<float *>(s_xy);
+    float *zmf = reinterpret_cast<float *>(s_zm);
     const int i = blockIdx.x * 256 + threadIdx.x;
     const Float4 me = targets[i < nt ? i : 0];
     float fx = 0.f, fy = 0.f, fz = 0.f, ps = 0.f;
+    v2f fx2 = {0.f, 0.f}, fy2 = {0.f, 0.f}, fz2 = {0.f, 0.f};
+    const v2f px2 = {me.x, me.x}, py2 = {me.y, me.y}, pz2 = {me.z, me.z}, e2 = {eps2, eps2};
     for (int t0 = 0; t0 < ns; t0 += 256) {
         const int c = min(256, ns - t0);
-        if ((int) threadIdx.x < c) s_src[threadIdx.x] = sources[t0 + threadIdx.x];
+        {
+            const int t = (int) threadIdx.x;
+            // a massless pad at the body's own distance scale keeps partial tiles branch-free
+            const Float4 s = t < c ? sources[t0 + t] : Float4{0.f, 0.f, 0.f, 0.f};
+            const int p = t >> 1, h = t & 1;
+            xyf[4 * p + h] = s.x; xyf[4 * p + 2 + h] = s.y;
+            zmf[4 * p + h] = s.z; zmf[4 * p + 2 + h] = s.w;
+        }
         __syncthreads();
+        const int np2 = (c + 1) >> 1;
         if (POT) {
-            for (int j = 0; j < c; ++j) {
-                const Float4 s = s_src[j];
-                const float dx = s.x - me.x, dy = s.y - me.y, dz = s.z - me.z;
-                const float t = fmaf(dz, dz, fmaf(dy, dy, dx * dx)) + eps2;
-                const float r = __builtin_amdgcn_rsqf(t);
-                const float mr = s.w * r;
-                ps += mr;
-                const float inv = mr * r * r;
-                fx = fmaf(dx, inv, fx); fy = fmaf(dy, inv, fy); fz = fmaf(dz, inv, fz);
+            for (int j = 0; j < np2; ++j) {
+                const v4f a = s_xy[j], b = s_zm[j];
+                const v2f dx = a.xy - px2, dy = a.zw - py2, dz = b.xy - pz2;
+                const v2f t = __builtin_elementwise_fma(
+                    dz, dz, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dx, dx, e2)));
+                const v2f r = {__builtin_amdgcn_rsqf(t.x), __builtin_amdgcn_rsqf(t.y)};
+                const v2f mr = b.zw * r;
+                ps += mr.x + mr.y;
+                const v2f inv = mr * r * r;
+                fx2 = __builtin_elementwise_fma(dx, inv, fx2);
+                fy2 = __builtin_elementwise_fma(dy, inv, fy2);
+                fz2 = __builtin_elementwise_fma(dz, inv, fz2);
             }
-        } else if (c == 256) {
-#pragma unroll 8
-            for (int j = 0; j < 256; ++j) interact(s_src[j], me.x, me.y, me.z, eps2, fx, fy, fz);
         } else {
-            for (int j = 0; j < c; ++j) interact(s_src[j], me.x, me.y, me.z, eps2, fx, fy, fz);
+#pragma unroll 8
+            for (int j = 0; j < np2; ++j) {
+                const v4f a = s_xy[j], b = s_zm[j];
+                const v2f dx = a.xy - px2, dy = a.zw - py2, dz = b.xy - pz2;
+                const v2f t = __builtin_elementwise_fma(
+                    dz, dz, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dx, dx, e2)));
+                const v2f t3 = t * t * t;
+                v2f inv = {__builtin_amdgcn_rsqf(t3.x), __builtin_amdgcn_rsqf(t3.y)};
+                inv *= b.zw;
+                fx2 = __builtin_elementwise_fma(dx, inv, fx2);
+                fy2 = __builtin_elementwise_fma(dy, inv, fy2);
+                fz2 = __builtin_elementwise_fma(dz, inv, fz2);
+            }
         }
         __syncthreads();
     }
+    fx = fx2.x + fx2.y; fy = fy2.x + fy2.y; fz = fz2.x + fz2.y;
     if (i < nt) {
         float rx = gravity * fx, ry = gravity * fy, rz = gravity * fz;
         if (accumulate) { rx += ax[i]; ry += ay[i]; rz += az[i]; }
