@@ -31,7 +31,8 @@ enum {
     NBODY_ERR_HIP = 2,      /* a HIP runtime call failed                         */
     NBODY_ERR_STATE = 3,    /* call sequence error (e.g. update before spawn)    */
     NBODY_ERR_DEVICE = 4,   /* a kernel reported an internal error (spin limit)  */
-    NBODY_ERR_IO = 5
+    NBODY_ERR_IO = 5,
+    NBODY_ERR_CAPACITY = 6  /* an output buffer of the caller was too small          */
 };
 
 /* nbody_params.flags */
@@ -199,6 +200,36 @@ int nbody_direct_sum(nbody_t *sim, float *ax, float *ay, float *az);
  * group_end = -1 restores the single-GPU behaviour. */
 int nbody_set_traversal_range(nbody_t *sim, int32_t group_begin, int32_t group_end);
 int nbody_finish_step(nbody_t *sim);
+
+/* Multi-GPU domain decomposition with a locally-essential-tree exchange.  The reference is
+ * single-GPU (its update() is src/cuda/simulation.cu:224-238); these four calls are what a
+ * one-process-per-GPU caller adds around nbody_update() when every GPU OWNS a fixed subset
+ * of the particles instead of holding all of them:
+ *   1. nbody_update() with nbody_set_traversal_range(0, ngroups): kick-drift, sort, build and
+ *      the traversal of the own tree, velocity kick deferred;
+ *   2. nbody_get_bbox() -> all-gather of the boxes;
+ *   3. nbody_let_export(): for every remote box, the (x,y,z,m) records -- centres of mass of
+ *      nodes the whole box accepts under the opening criterion, and the particles of leaves
+ *      it cannot -- that the remote bodies need from this tree; all-to-all of the records;
+ *   4. nbody_set_sources_dev() on a second handle builds a tree over the received records,
+ *      nbody_traverse_from(own, second, 1) adds their attraction, nbody_finish_step() kicks.
+ *
+ * nbody_get_bbox: lo_hi[0..2] = min, lo_hi[3..5] = max of the handle's current positions.
+ * nbody_let_export: boxes = nboxes x 6 floats (host, same layout), nboxes <= 256; records of
+ *   box b are written to out_dev + 4*capacity*b (device, float4 each, order unspecified);
+ *   counts[b] (host) = records box b needs.  NBODY_ERR_CAPACITY if any count > capacity
+ *   (counts are still valid: call again with a larger buffer).
+ * nbody_set_sources_dev: replace the handle's particles by `count` (x,y,z,m) device records,
+ *   0 <= count <= num_points, velocities zero, then sort + build + centres of mass.  The
+ *   handle keeps that size until the next set_sources/set_state/spawn.
+ * nbody_traverse_from: accelerations of `sim`'s particles due to the tree of `sources` (same
+ *   device and key width; theta/softening/gravity of `sim`); added to ax/ay/az when
+ *   accumulate != 0. */
+int nbody_get_bbox(nbody_t *sim, float *lo_hi);
+int nbody_let_export(nbody_t *sim, const float *boxes, int32_t nboxes, float *out_dev,
+                     int32_t capacity, int32_t *counts);
+int nbody_set_sources_dev(nbody_t *sim, const float *posm_dev, int32_t count);
+int nbody_traverse_from(nbody_t *sim, nbody_t *sources, int32_t accumulate);
 
 #ifdef __cplusplus
 }

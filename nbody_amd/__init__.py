@@ -18,6 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnbody_mi355.so")
 
 OK = 0
+ERR_CAPACITY = 6
 FLAG_TIMING = 1 << 0
 FLAG_NO_FUSED_VEL = 1 << 1
 FLAG_DEBUG_WALK_ONLY = 1 << 8
@@ -79,7 +80,8 @@ EXPORTS = [
     "nbody_get_num_octree_nodes", "nbody_write_validation_history", "nbody_get_state",
     "nbody_get_device_ptrs", "nbody_get_tree_counts", "nbody_get_octree", "nbody_get_timings",
     "nbody_direct_sum_dev", "nbody_direct_sum", "nbody_set_traversal_range", "nbody_finish_step",
-    "nbody_get_validation_history",
+    "nbody_get_validation_history", "nbody_get_bbox", "nbody_let_export", "nbody_set_sources_dev",
+    "nbody_traverse_from",
 ]
 
 _lib = None
@@ -126,6 +128,11 @@ def load_library() -> C.CDLL:
     dp = C.POINTER(C.c_double)
     lib.nbody_get_validation_history.argtypes = [C.c_void_p, dp, dp, dp, C.c_int32,
                                                  C.POINTER(C.c_int32)]
+    lib.nbody_get_bbox.argtypes = [C.c_void_p, fp]
+    lib.nbody_let_export.argtypes = [C.c_void_p, fp, C.c_int32, C.c_void_p, C.c_int32,
+                                     C.POINTER(C.c_int32)]
+    lib.nbody_set_sources_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    lib.nbody_traverse_from.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     _lib = lib
     return lib
 
@@ -312,3 +319,34 @@ class Simulation:
 
     def finish_step(self):
         self._check(self._lib.nbody_finish_step(self._h))
+
+    # -- multi-GPU locally-essential-tree exchange ------------------------------
+    def get_bbox(self) -> np.ndarray:
+        """(lo_x, lo_y, lo_z, hi_x, hi_y, hi_z) of the current positions."""
+        out = np.empty(6, np.float32)
+        self._check(self._lib.nbody_get_bbox(self._h, _fptr(out)))
+        return out
+
+    def let_export(self, boxes, out_dev_ptr: int, capacity: int) -> np.ndarray:
+        """Writes the records every box needs to out_dev_ptr + 16*capacity*b; returns the
+        per-box record counts.  Raises CapacityError (with .counts) if one exceeds capacity."""
+        boxes = np.ascontiguousarray(boxes, np.float32).reshape(-1, 6)
+        counts = np.zeros(len(boxes), np.int32)
+        rc = self._lib.nbody_let_export(self._h, _fptr(boxes), len(boxes), out_dev_ptr, capacity,
+                                        counts.ctypes.data_as(C.POINTER(C.c_int32)))
+        if rc == ERR_CAPACITY:
+            raise CapacityError(counts)
+        self._check(rc)
+        return counts
+
+    def set_sources_dev(self, posm_dev_ptr: int, count: int):
+        self._check(self._lib.nbody_set_sources_dev(self._h, posm_dev_ptr, count))
+
+    def traverse_from(self, sources: "Simulation", accumulate: bool = True):
+        self._check(self._lib.nbody_traverse_from(self._h, sources._h, 1 if accumulate else 0))
+
+
+class CapacityError(RuntimeError):
+    def __init__(self, counts):
+        super().__init__(f"record buffer too small: need {int(max(counts))} per box")
+        self.counts = counts

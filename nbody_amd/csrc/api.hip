@@ -53,7 +53,7 @@ void free_all(Sim *s)
     F(s->bfs); F(s->octid); F(s->o_depth); F(s->o_first_child); F(s->o_num_children); F(s->o_lb);
     F(s->o_le); F(s->o_level); F(s->o_pb); F(s->o_pe); F(s->o_parent); F(s->o_size); F(s->o_wsum);
     F(s->nodeA); F(s->nodeB); F(s->list_len); F(s->inter_dev); F(s->trav_tail);
-    F(s->tw_posm); F(s->tw_pot); F(s->ds_pot);
+    F(s->tw_posm); F(s->tw_pot); F(s->ds_pot); F(s->let_boxes); F(s->let_counts);
     for (int k = 0; k < 3; ++k) { F(s->tw_v[k]); F(s->tw_vh[k]); F(s->tw_a[k]); F(s->ds_a[k]); }
     if (s->counts_host) (void) hipHostFree(s->counts_host);
     for (int r = 0; r < TIMING_RING; ++r)
@@ -64,7 +64,7 @@ void free_all(Sim *s)
 
 int alloc_all(Sim *s)
 {
-    const size_t n = (size_t) s->n;
+    const size_t n = (size_t) s->cap;
     for (int i = 0; i < 2; ++i) {
         NB_HIP(s, dalloc(&s->x[i], n)); NB_HIP(s, dalloc(&s->y[i], n)); NB_HIP(s, dalloc(&s->z[i], n));
         NB_HIP(s, dalloc(&s->m[i], n));
@@ -139,6 +139,8 @@ int alloc_all(Sim *s)
         NB_HIP(s, dalloc(&s->trav_tail, 1));
         NB_HIP(s, hipMemcpy(s->trav_tail, &t, sizeof t, hipMemcpyHostToDevice));
     }
+    NB_HIP(s, dalloc(&s->let_boxes, (size_t) 6 * LET_MAX_BOXES));
+    NB_HIP(s, dalloc(&s->let_counts, (size_t) LET_MAX_BOXES + 8));
     NB_HIP(s, dalloc(&s->inter_dev, (size_t) TIMING_RING));
     NB_HIP(s, hipMemsetAsync(s->inter_dev, 0, TIMING_RING * 8, s->stream));
     if (s->p.num_steps_validator > 0) {
@@ -298,6 +300,7 @@ int post_spawn(Sim *s)
 int upload_state(Sim *s, const float *x, const float *y, const float *z, const float *vx,
                  const float *vy, const float *vz, const float *m)
 {
+    s->n = s->cap;
     const size_t n = (size_t) s->n, b = n * 4;
     const int c = s->cur;
     std::vector<uint32_t> ids(n);
@@ -338,6 +341,7 @@ int upload_state(Sim *s, const float *x, const float *y, const float *z, const f
 
 int spawn(Sim *s, int kind, float p0, float p1)
 {
+    s->n = s->cap;
     const size_t n = (size_t) s->n;
     std::vector<float> x(n), y(n), z(n), vx(n), vy(n), vz(n), m(n);
     int rc = sample_ic(kind, s->n, s->p.seed, s->p.domain_size, s->p.gravity, p0, p1, x.data(),
@@ -453,6 +457,7 @@ int nbody_create(const nbody_params *params, nbody_t **out)
     if (!s) return NBODY_ERR_INVALID;
     s->p = p;
     s->n = p.num_points;
+    s->cap = p.num_points;
     s->group = p.traversal_group_size;
     s->key_bytes = p.morton_bits == 10 ? 4 : 8;
     int dev = p.device_id;
@@ -757,6 +762,89 @@ int nbody_direct_sum(nbody_t *h, float *ax, float *ay, float *az)
     if (e == hipSuccess && ay) e = hipMemcpy(ay, d + n, n * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess && az) e = hipMemcpy(az, d + 2 * n, n * 4, hipMemcpyDeviceToHost);
     (void) hipFree(d);
+    NB_HIP(s, e);
+    return NBODY_OK;
+}
+
+// ---- multi-GPU locally-essential-tree exchange (no counterpart in the single-GPU reference) ----
+
+int nbody_get_bbox(nbody_t *h, float *lo_hi)
+{
+    NB_ENTER(h);
+    if (!lo_hi) return fail(s, NBODY_ERR_INVALID, "null output");
+    if (!s->spawned || s->n < 1) return fail(s, NBODY_ERR_STATE, "bbox of an empty handle");
+    uint32_t *box = s->let_counts + LET_MAX_BOXES;
+    const uint32_t init[6] = {0x7f7fffffu, 0x7f7fffffu, 0x7f7fffffu, 0u, 0u, 0u};
+    NB_HIP(s, hipMemcpyAsync(box, init, sizeof init, hipMemcpyHostToDevice, s->stream));
+    NB_HIP(s, launch_bbox(s, box));
+    NB_HIP(s, hipMemcpyAsync(lo_hi, box, 6 * 4, hipMemcpyDeviceToHost, s->stream));
+    NB_HIP(s, hipStreamSynchronize(s->stream));
+    return NBODY_OK;
+}
+
+int nbody_let_export(nbody_t *h, const float *boxes, int32_t nboxes, float *out_dev,
+                     int32_t capacity, int32_t *counts)
+{
+    NB_ENTER(h);
+    if (!boxes || !out_dev || !counts || nboxes < 0 || nboxes > LET_MAX_BOXES || capacity < 0)
+        return fail(s, NBODY_ERR_INVALID, "let_export: bad arguments");
+    if (!s->spawned || s->n < 1) return fail(s, NBODY_ERR_STATE, "let_export before spawn/set_state");
+    if (nboxes == 0) return NBODY_OK;
+    NB_HIP(s, hipMemcpyAsync(s->let_boxes, boxes, (size_t) nboxes * 24, hipMemcpyHostToDevice, s->stream));
+    NB_HIP(s, hipMemsetAsync(s->let_counts, 0, (size_t) nboxes * 4, s->stream));
+    NB_HIP(s, launch_let_export(s, s->let_boxes, nboxes, reinterpret_cast<Float4 *>(out_dev),
+                                capacity, s->let_counts));
+    NB_HIP(s, hipMemcpyAsync(counts, s->let_counts, (size_t) nboxes * 4, hipMemcpyDeviceToHost, s->stream));
+    NB_HIP(s, hipStreamSynchronize(s->stream));
+    for (int i = 0; i < nboxes; ++i)
+        if (counts[i] > capacity)
+            return fail(s, NBODY_ERR_CAPACITY, "let_export: a box needs more records than capacity");
+    return NBODY_OK;
+}
+
+int nbody_set_sources_dev(nbody_t *h, const float *posm_dev, int32_t count)
+{
+    NB_ENTER(h);
+    if (count < 0 || count > s->cap || (count > 0 && !posm_dev))
+        return fail(s, NBODY_ERR_INVALID, "set_sources: count outside [0, num_points]");
+    if (s->p.num_steps_validator > 0)
+        return fail(s, NBODY_ERR_STATE, "set_sources on a handle with a validator");
+    s->n = count;
+    s->pending_vel = false;
+    if (count == 0) { s->spawned = false; return NBODY_OK; }
+    NB_HIP(s, launch_unpack_sources(s, reinterpret_cast<const Float4 *>(posm_dev), count));
+    NB_HIP(s, launch_morton_only(s));
+    int rc = build_after_encode(s, false);
+    if (rc) return rc;
+    NB_HIP(s, launch_build(s));
+    NB_HIP(s, launch_com(s));
+    s->spawned = true;
+    return fetch_counts(s);
+}
+
+int nbody_traverse_from(nbody_t *h, nbody_t *sources, int32_t accumulate)
+{
+    NB_ENTER(h);
+    if (!sources) return fail(s, NBODY_ERR_INVALID, "null sources");
+    Sim *src = reinterpret_cast<Sim *>(sources);
+    if (!s->spawned) return fail(s, NBODY_ERR_STATE, "traverse_from before spawn/set_state");
+    if (src->device != s->device || src->key_bytes != s->key_bytes)
+        return fail(s, NBODY_ERR_INVALID, "traverse_from: handles differ in device or key width");
+    const size_t b = (size_t) s->n * 4;
+    if (src->n == 0) {  // nothing to add
+        if (!accumulate) {
+            NB_HIP(s, hipMemsetAsync(s->ax, 0, b, s->stream));
+            NB_HIP(s, hipMemsetAsync(s->ay, 0, b, s->stream));
+            NB_HIP(s, hipMemsetAsync(s->az, 0, b, s->stream));
+        }
+        return NBODY_OK;
+    }
+    if (!src->spawned) return fail(s, NBODY_ERR_STATE, "traverse_from: sources hold no tree");
+    if (src != s) NB_HIP(s, hipStreamSynchronize(src->stream));
+    const int g0 = s->trav_g0, g1 = s->trav_g1;
+    s->trav_g1 = -1;  // all groups
+    hipError_t e = launch_traverse_from(s, src, accumulate != 0);
+    s->trav_g0 = g0; s->trav_g1 = g1;
     NB_HIP(s, e);
     return NBODY_OK;
 }

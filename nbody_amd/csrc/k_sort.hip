@@ -156,8 +156,9 @@ template <typename KeyT, int NPASS>
 static hipError_t sort_impl(Sim *s)
 {
     const int n = s->n;
-    const int tiles = s->sort_tiles;
-    hipError_t e = hipMemsetAsync(s->ghist, 0, s->sort_status_bytes, s->stream);
+    const int tiles = (n + SORT_TILE - 1) / SORT_TILE;   // <= s->sort_tiles (sized for cap)
+    const size_t zbytes = (8 * 256 + 16 + (size_t) NPASS * tiles * 256) * sizeof(uint32_t);
+    hipError_t e = hipMemsetAsync(s->ghist, 0, zbytes, s->stream);
     if (e != hipSuccess) return e;
     // layout of the zeroed block: ghist[8*256] | tickets[8] (+pad to 16) | status[P][tiles][256]
     uint32_t *tickets = s->ghist + 8 * 256;

@@ -55,9 +55,10 @@ struct alignas(16) WaveLds {
 
 template <int G, bool FUSE_VEL, bool WALK_ONLY>
 __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
-    int n, int g0, int g1, const Float4 *__restrict__ posm, const v8f *__restrict__ posm2,
-    const Float4 *__restrict__ nodeA, const NodeB *__restrict__ nodeB, float theta, float eps2,
-    float gravity, float domain, float dt, float keep, const TravTail *__restrict__ tail, int cur)
+    int n, int g0, int g1, const Float4 *__restrict__ body_posm, const Float4 *__restrict__ posm,
+    const v8f *__restrict__ posm2, const Float4 *__restrict__ nodeA,
+    const NodeB *__restrict__ nodeB, float theta, float eps2, float gravity, float domain,
+    float dt, float keep, const TravTail *__restrict__ tail, int cur, int accumulate)
 {
     __shared__ WaveLds lds[TRAV_WAVES];
 
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
 
     const int b = g * G + lane;
     const bool active = lane < G && b < n;
-    const Float4 me = posm[active ? b : g * G];
+    const Float4 me = body_posm[active ? b : g * G];
     if (lane < G) {
         const int p = lane >> 1, h = lane & 1;
         bxyf[4 * p + h] = me.x;
@@ -277,7 +278,8 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
 
     if (lane == 0) tail->list_len[g] = total;
     if (active) {
-        const float axv = gravity * fx, ayv = gravity * fy, azv = gravity * fz;
+        float axv = gravity * fx, ayv = gravity * fy, azv = gravity * fz;
+        if (accumulate) { axv += tail->ax[b]; ayv += tail->ay[b]; azv += tail->az[b]; }
         tail->ax[b] = axv; tail->ay[b] = ayv; tail->az[b] = azv;
         if (FUSE_VEL) {
             tail->vx[cur][b] = fmaf(0.5f * axv, dt, tail->vhx[cur][b]) * keep;
@@ -386,7 +388,8 @@ __global__ __launch_bounds__(256) void k_direct(const Float4 *__restrict__ targe
     }
 }
 
-hipError_t launch_traverse(Sim *s, bool fuse_vel)
+// Bodies of `s` against the tree of `src` (the same handle for an ordinary step).
+static hipError_t traverse_impl(Sim *s, Sim *src, bool fuse_vel, int acc_flag)
 {
     const int ngroups = (s->n + s->group - 1) / s->group;
     const int g0 = s->trav_g1 < 0 ? 0 : s->trav_g0;
@@ -398,9 +401,9 @@ hipError_t launch_traverse(Sim *s, bool fuse_vel)
         const float keep = 1.0f - s->p.velocity_dampening;
 #define NB_TRAV(GG, FV, WO)                                                                      \
     hipLaunchKernelGGL((k_traverse<GG, FV, WO>), dim3(grid), dim3(64 * TRAV_WAVES), 0, s->stream,    \
-                       s->n, g0, g1, s->posm, (const v8f *) s->posm2, s->nodeA, s->nodeB,            \
-                       s->p.theta, eps2, s->p.gravity, s->p.domain_size, s->p.dt, keep,              \
-                       s->trav_tail, c)
+                       s->n, g0, g1, s->posm, src->posm, (const v8f *) src->posm2, src->nodeA,       \
+                       src->nodeB, s->p.theta, eps2, s->p.gravity, s->p.domain_size, s->p.dt, keep,  \
+                       s->trav_tail, c, acc_flag)
         const bool walk_only = (s->p.flags & NBODY_FLAG_DEBUG_WALK_ONLY) != 0;
         if (walk_only) {
             if (s->group == 64) NB_TRAV(64, false, true); else NB_TRAV(32, false, true);
@@ -412,6 +415,13 @@ hipError_t launch_traverse(Sim *s, bool fuse_vel)
 #undef NB_TRAV
     }
     return hipGetLastError();
+}
+
+hipError_t launch_traverse(Sim *s, bool fuse_vel) { return traverse_impl(s, s, fuse_vel, 0); }
+
+hipError_t launch_traverse_from(Sim *bodies, Sim *sources, bool accumulate)
+{
+    return traverse_impl(bodies, sources, false, accumulate ? 1 : 0);
 }
 
 hipError_t launch_count_interactions(Sim *s, unsigned long long *out)

@@ -16,6 +16,7 @@ constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 16;                      // elements per thread in compaction tiles
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+constexpr int LET_MAX_BOXES = 256;
 constexpr int TRAV_WAVES = 4;                       // groups (waves) per traversal workgroup
 constexpr int TRAV_STACK = 512;                     // LDS inner-node stack entries per wave
 constexpr int TRAV_LEAF_STACK = 640;                // LDS leaf stack entries per wave
@@ -52,7 +53,8 @@ struct Counts {
 
 struct Sim {
     nbody_params p{};
-    int n = 0;            // particles
+    int n = 0;            // particles currently held (<= cap)
+    int cap = 0;          // capacity every array is sized for (= params.num_points)
     int group = 64;
     int key_bytes = 4;    // 4 (B=10) or 8 (B=21)
     int device = 0;
@@ -114,6 +116,9 @@ struct Sim {
     NodeB *nodeB = nullptr;
     uint32_t *list_len = nullptr; // [ceil(n/group)]
     TravTail *trav_tail = nullptr;
+    // LET exchange scratch
+    float *let_boxes = nullptr;      // [64][6] device copy of the remote boxes
+    uint32_t *let_counts = nullptr;  // [64] + 6 words of bounding box
 
     // sharded traversal
     int trav_g0 = 0, trav_g1 = -1;
@@ -155,5 +160,10 @@ hipError_t launch_vel_kick_raw(int n, float dt, float keep, const float *vhx, co
                                const float *vhz, const float *ax, const float *ay, const float *az,
                                float *vx, float *vy, float *vz, hipStream_t st);
 hipError_t launch_count_interactions(Sim *s, unsigned long long *out);
+hipError_t launch_traverse_from(Sim *bodies, Sim *sources, bool accumulate);
+hipError_t launch_bbox(Sim *s, uint32_t *box_dev);
+hipError_t launch_let_export(Sim *s, const float *boxes_dev, int nboxes, Float4 *out, int cap,
+                             uint32_t *out_count);
+hipError_t launch_unpack_sources(Sim *s, const Float4 *src, int n);
 
 }  // namespace nb

@@ -13,6 +13,15 @@ the two exchange steps the step path has when it is spread over the GPUs of a no
   flight while the current one is being summed), each rank accumulating the accelerations of
   its own bodies.  No reduction is needed.
 
+* LetStepper -- Barnes-Hut step with DOMAIN DECOMPOSITION.  Every rank owns a fixed subset of
+  the particles (one box of an orthogonal recursive bisection of the initial conditions), builds a tree over
+  them only and traverses it; what its bodies need from the other domains arrives as a
+  locally-essential tree: an all-gather of the P bounding boxes (24 bytes each), then ONE
+  all-to-all of (x,y,z,m) records -- the centres of mass of remote nodes the whole box may
+  approximate, and the particles of remote leaves it may not.  A second tree is built over
+  the received records and traversed for the own bodies.  Memory, build and traversal all
+  scale with N/P; the exchanged volume is a surface term.
+
 The compute itself is injected (`backend` / `tile_kernel`), so the same choreography runs on
 GPUs through libnbody_mi355.so and in the CPU tests through the host oracle.
 """
@@ -83,6 +92,73 @@ class ShardedTraversal:
             torch.cuda.current_stream(t.device).synchronize()
 
 
+class LetStepper:
+    """backend must provide:
+        update()                      kick-drift, sort, build, own-tree traversal (kick deferred)
+        bbox()                        6 floats (lo xyz, hi xyz) of the own particles
+        let_export(boxes)             boxes: (k, 6) float32 array -> list of k (cnt_i, 4)
+                                      float32 torch tensors on the backend's device
+        add_remote(records)           (cnt, 4) tensor: build a tree over it, add its attraction
+        finish_step()                 velocity kick
+        device                        torch device of the exchanged tensors
+    """
+
+    def __init__(self, backend, process_group=None):
+        self.b = backend
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group)
+        self.rank = dist.get_rank(process_group)
+        self.last_sent = 0
+        self.last_received = 0
+
+    def step(self):
+        b, W, me = self.b, self.world, self.rank
+        b.update()
+        dev = b.device
+        box = torch.as_tensor(b.bbox(), dtype=torch.float32).to(dev)
+        boxes = torch.empty(W * 6, dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(boxes, box, group=self.pg)
+        boxes = boxes.view(W, 6)
+        others = [r for r in range(W) if r != me]
+        recs = b.let_export(boxes.cpu().numpy()[others]) if others else []
+        send_rows = [0] * W
+        for r, t in zip(others, recs):
+            send_rows[r] = int(t.shape[0])
+        sc = torch.tensor(send_rows, dtype=torch.int64, device=dev)
+        rc = torch.empty_like(sc)
+        dist.all_to_all_single(rc, sc, group=self.pg)
+        recv_rows = [int(v) for v in rc.cpu()]
+        send = torch.cat(recs) if recs else torch.empty(0, 4, dtype=torch.float32, device=dev)
+        recv = torch.empty(sum(recv_rows), 4, dtype=torch.float32, device=dev)
+        dist.all_to_all_single(recv, send.contiguous(), recv_rows, send_rows, group=self.pg)
+        if recv.is_cuda:  # the library works on its own stream: finish RCCL before the build
+            torch.cuda.current_stream(recv.device).synchronize()
+        self.last_sent, self.last_received = sum(send_rows), sum(recv_rows)
+        b.add_remote(recv)
+        b.finish_step()
+
+
+def domain_slices(x, y, z, world):
+    """Index arrays of `world` domains of (nearly) equal particle count with disjoint, tight
+    bounding boxes: orthogonal recursive bisection of the given positions (numpy), each cut
+    across the longest axis of the piece, in the ratio of the ranks on either side.  This is
+    the initial ownership of a LetStepper run."""
+    import numpy as np
+    pos = np.stack([np.asarray(a, np.float64) for a in (x, y, z)], 1)
+
+    def cut(idx, parts):
+        if parts == 1:
+            return [np.sort(idx)]
+        left = parts // 2
+        p = pos[idx]
+        axis = int(np.argmax(p.max(0) - p.min(0)))
+        k = len(idx) * left // parts
+        order = np.argsort(p[:, axis], kind="stable")
+        return cut(idx[order[:k]], left) + cut(idx[order[k:]], parts - left)
+
+    return cut(np.arange(len(pos)), world)
+
+
 def ring_direct_sum(local_posm: torch.Tensor, tile_kernel, process_group=None):
     """local_posm: (n_local, 4) float32 tensor of this rank's bodies (x, y, z, m); all ranks
     hold the same n_local.  tile_kernel(targets, sources, accumulate) adds the accelerations
@@ -150,6 +226,66 @@ class GpuBackend:
 
     def acc_tensors(self):
         return self._acc
+
+    def finish_step(self):
+        self.sim.finish_step()
+
+
+class GpuLetBackend:
+    """LetStepper backend over two nbody_amd.Simulation handles on one GPU: `sim` holds the
+    own particles, `remote` (created here, grown on demand) the imported records."""
+
+    def __init__(self, sim, device, record_capacity=None, exchange_device=None):
+        import nbody_amd as nb
+        self._nb = nb
+        self.sim = sim
+        self.gpu = torch.device(device)
+        # where the exchanged tensors live: the GPU itself under RCCL; "cpu" lets several
+        # ranks share one GPU over gloo (tests)
+        self.device = torch.device(exchange_device) if exchange_device else self.gpu
+        self.n = sim.params.num_points
+        g = sim.params.traversal_group_size
+        sim.set_traversal_range(0, (self.n + g - 1) // g)   # defer the kick to finish_step()
+        self.cap = int(record_capacity or max(4096, self.n // 4))
+        self._buf = None
+        self.remote = None
+        self._remote_cap = 0
+
+    def update(self):
+        self.sim.update()
+
+    def bbox(self):
+        return self.sim.get_bbox()
+
+    def let_export(self, boxes):
+        k = len(boxes)
+        while True:
+            if self._buf is None or self._buf.shape[0] < k or self._buf.shape[1] < self.cap:
+                self._buf = torch.empty(k, self.cap, 4, dtype=torch.float32, device=self.gpu)
+            try:
+                counts = self.sim.let_export(boxes, self._buf.data_ptr(), self._buf.shape[1])
+                break
+            except self._nb.CapacityError as e:
+                self.cap = int(max(e.counts) * 1.25) + 1024
+                self._buf = None
+        return [self._buf[i, :int(c)].to(self.device) for i, c in enumerate(counts)]
+
+    def add_remote(self, records):
+        cnt = int(records.shape[0])
+        records = records.to(self.gpu).contiguous()
+        if records.is_cuda:
+            torch.cuda.current_stream(self.gpu).synchronize()
+        if cnt > self._remote_cap:
+            if self.remote is not None:
+                self.remote.close()
+            self._remote_cap = max(int(cnt * 1.25) + 1024, self.n // 2)
+            p = self._nb.Params(**{**self.sim.params.__dict__, "num_points": self._remote_cap,
+                                   "num_steps_validator": 0, "flags": 0})
+            self.remote = self._nb.Simulation(p)
+        if self.remote is None:
+            return
+        self.remote.set_sources_dev(records.data_ptr() if cnt else 0, cnt)
+        self.sim.traverse_from(self.remote, accumulate=True)
 
     def finish_step(self):
         self.sim.finish_step()

@@ -441,15 +441,18 @@ void orc_com(int n_oct, const int32_t *first_child, const int32_t *num_children,
 // first.  list_len[g] = number of (com|point) sources the group interacted
 // with; interactions = sum_g list_len[g] * bodies_in_group(g).
 // ---------------------------------------------------------------------------
-void orc_traverse(int n, int group, const float *x, const float *y, const float *z,
-                  const float *m, int n_oct, const int32_t *first_child,
+// Core: bodies (bx,by,bz; nb of them, grouped by `group`) against the tree whose points are
+// (x,y,z,m).  orc_traverse passes the same arrays for both; orc_traverse_from passes the
+// bodies of one domain and the tree built over records imported from other domains.
+static void traverse_core(int n, int group, const float *bx, const float *by, const float *bz,
+                          const float *x, const float *y, const float *z,
+                  const float *m, const int32_t *first_child,
                   const int32_t *num_children, const int32_t *points_begin,
                   const int32_t *points_end, const float *size, const float *comx,
                   const float *comy, const float *comz, const float *mass, float theta,
                   float eps2, float gravity, float domain, float *ax, float *ay, float *az,
-                  uint32_t *list_len)
+                  uint32_t *list_len, int accumulate)
 {
-    (void) n_oct;
     const int ngroups = (n + group - 1) / group;
 #pragma omp parallel
     {
@@ -471,7 +474,7 @@ void orc_traverse(int n, int group, const float *x, const float *y, const float 
                 if (nc == 0) {
                     for (int p = points_begin[node]; p <= points_end[node]; ++p) {
                         for (int b = b0; b < b1; ++b)
-                            pair_force(x[b], y[b], z[b], x[p], y[p], z[p], m[p], fx[b - b0],
+                            pair_force(bx[b], by[b], bz[b], x[p], y[p], z[p], m[p], fx[b - b0],
                                        fy[b - b0], fz[b - b0], eps2);
                         ++cnt;
                     }
@@ -479,13 +482,13 @@ void orc_traverse(int n, int group, const float *x, const float *y, const float 
                 }
                 float dmin = domain * domain * 3.0f;
                 for (int b = b0; b < b1; ++b) {
-                    float d = dist_sq(x[b], y[b], z[b], comx[node], comy[node], comz[node]);
+                    float d = dist_sq(bx[b], by[b], bz[b], comx[node], comy[node], comz[node]);
                     if (d <= dmin) dmin = d;
                 }
                 const float sz = size[node];
                 if (sz * sz / dmin < theta * theta) {
                     for (int b = b0; b < b1; ++b)
-                        pair_force(x[b], y[b], z[b], comx[node], comy[node], comz[node],
+                        pair_force(bx[b], by[b], bz[b], comx[node], comy[node], comz[node],
                                    mass[node], fx[b - b0], fy[b - b0], fz[b - b0], eps2);
                     ++cnt;
                 } else {
@@ -494,13 +497,81 @@ void orc_traverse(int n, int group, const float *x, const float *y, const float 
                 }
             }
             for (int b = b0; b < b1; ++b) {
-                ax[b] = gravity * fx[b - b0];
-                ay[b] = gravity * fy[b - b0];
-                az[b] = gravity * fz[b - b0];
+                float rx = gravity * fx[b - b0], ry = gravity * fy[b - b0], rz = gravity * fz[b - b0];
+                if (accumulate) { rx += ax[b]; ry += ay[b]; rz += az[b]; }
+                ax[b] = rx; ay[b] = ry; az[b] = rz;
             }
             list_len[g] = cnt;
         }
     }
+}
+
+void orc_traverse(int n, int group, const float *x, const float *y, const float *z,
+                  const float *m, int n_oct, const int32_t *first_child,
+                  const int32_t *num_children, const int32_t *points_begin,
+                  const int32_t *points_end, const float *size, const float *comx,
+                  const float *comy, const float *comz, const float *mass, float theta,
+                  float eps2, float gravity, float domain, float *ax, float *ay, float *az,
+                  uint32_t *list_len)
+{
+    (void) n_oct;
+    traverse_core(n, group, x, y, z, x, y, z, m, first_child, num_children, points_begin,
+                  points_end, size, comx, comy, comz, mass, theta, eps2, gravity, domain, ax, ay,
+                  az, list_len, 0);
+}
+
+// ---------------------------------------------------------------------------
+// Multi-GPU locally-essential-tree exchange.  NOT a restatement of the reference (it is
+// single-GPU): these two functions are an independent, top-down host formulation of what
+// libnbody_mi355.so's nbody_traverse_from / nbody_let_export compute, used to check them.
+// ---------------------------------------------------------------------------
+void orc_traverse_from(int nb, int group, const float *bx, const float *by, const float *bz,
+                       const float *x, const float *y, const float *z, const float *m,
+                       const int32_t *first_child, const int32_t *num_children,
+                       const int32_t *points_begin, const int32_t *points_end,
+                       const float *size, const float *comx, const float *comy,
+                       const float *comz, const float *mass, float theta, float eps2,
+                       float gravity, float domain, float *ax, float *ay, float *az,
+                       uint32_t *list_len, int accumulate)
+{
+    traverse_core(nb, group, bx, by, bz, x, y, z, m, first_child, num_children, points_begin,
+                  points_end, size, comx, comy, comz, mass, theta, eps2, gravity, domain, ax, ay,
+                  az, list_len, accumulate);
+}
+
+// Records (x,y,z,m) a remote domain with bounding box `box` (lo xyz, hi xyz) needs from this
+// tree: depth-first from the root; a node with children whose size^2 / d^2 < theta^2, d the
+// distance from the box to the node's centre of mass, contributes (com, mass); a node
+// without children contributes its points; anything else is opened.  Returns the number of
+// records; writes at most `cap` of them.
+int orc_let_export(const int32_t *first_child, const int32_t *num_children,
+                   const int32_t *points_begin, const int32_t *points_end, const float *size,
+                   const float *comx, const float *comy, const float *comz, const float *mass,
+                   const float *x, const float *y, const float *z, const float *m,
+                   const float *box, float theta, float *out, int cap)
+{
+    int cnt = 0;
+    auto emit = [&](float a, float b, float c, float d) {
+        if (cnt < cap) { out[4 * cnt] = a; out[4 * cnt + 1] = b; out[4 * cnt + 2] = c; out[4 * cnt + 3] = d; }
+        ++cnt;
+    };
+    std::vector<int> stack{0};
+    while (!stack.empty()) {
+        const int o = stack.back();
+        stack.pop_back();
+        if (num_children[o] == 0) {
+            for (int p = points_begin[o]; p <= points_end[o]; ++p) emit(x[p], y[p], z[p], m[p]);
+            continue;
+        }
+        const float dx = std::max(0.0f, std::max(box[0] - comx[o], comx[o] - box[3]));
+        const float dy = std::max(0.0f, std::max(box[1] - comy[o], comy[o] - box[4]));
+        const float dz = std::max(0.0f, std::max(box[2] - comz[o], comz[o] - box[5]));
+        const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        if (size[o] * size[o] / d2 < theta * theta) emit(comx[o], comy[o], comz[o], mass[o]);
+        else
+            for (int c = first_child[o]; c < first_child[o] + num_children[o]; ++c) stack.push_back(c);
+    }
+    return cnt;
 }
 
 // ---------------------------------------------------------------------------

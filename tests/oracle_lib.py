@@ -35,6 +35,7 @@ def lib() -> C.CDLL:
     L.orc_energy_f64.restype = C.c_double
     L.orc_sim_create.restype = C.c_void_p
     L.orc_num_threads.restype = C.c_int
+    L.orc_let_export.restype = C.c_int
     _lib = L
     return L
 
@@ -124,6 +125,45 @@ def traverse(tree, comd, x, y, z, m, group, theta, eps, gravity, domain):
                        C.c_float(theta), C.c_float(np.float32(eps) * np.float32(eps)),
                        C.c_float(gravity), C.c_float(domain), _p(ax), _p(ay), _p(az), _p(ll))
     return ax, ay, az, ll
+
+
+def _tree_args(tree, comd):
+    i32 = lambda k: _p(np.ascontiguousarray(tree[k], np.int32))
+    a = [np.ascontiguousarray(comd[k], np.float32) for k in ("comx", "comy", "comz", "mass")]
+    size = np.ascontiguousarray(tree["size"], np.float32)
+    keep = a + [size]
+    return [i32("first_child"), i32("num_children"), i32("points_begin"), i32("points_end"),
+            _p(size)] + [_p(v) for v in a], keep
+
+
+def traverse_from(bodies, tree, comd, x, y, z, m, group, theta, eps, gravity, domain, acc=None):
+    """Accelerations of `bodies` = (bx, by, bz) due to the tree over the points (x, y, z, m);
+    acc = (ax, ay, az) float32 arrays to add to (None: fresh result)."""
+    bx, by, bz = (_f32(b) for b in bodies)
+    x, y, z, m = _f32(x), _f32(y), _f32(z), _f32(m)
+    nb = bx.size
+    out = [np.zeros(nb, np.float32) for _ in range(3)] if acc is None else [_f32(a).copy() for a in acc]
+    ll = np.empty((nb + group - 1) // group, np.uint32)
+    targs, keep = _tree_args(tree, comd)
+    lib().orc_traverse_from(C.c_int(nb), C.c_int(group), _p(bx), _p(by), _p(bz), _p(x), _p(y), _p(z),
+                            _p(m), *targs, C.c_float(theta),
+                            C.c_float(np.float32(eps) * np.float32(eps)), C.c_float(gravity),
+                            C.c_float(domain), *[_p(o) for o in out], _p(ll),
+                            C.c_int(0 if acc is None else 1))
+    return out[0], out[1], out[2], ll
+
+
+def let_export(tree, comd, x, y, z, m, box, theta):
+    """(k, 4) float32 records a domain with bounding box `box` needs from this tree."""
+    x, y, z, m = _f32(x), _f32(y), _f32(z), _f32(m)
+    box = _f32(box)
+    targs, keep = _tree_args(tree, comd)
+    cap = x.size + tree["n_oct"]
+    out = np.empty((cap, 4), np.float32)
+    k = lib().orc_let_export(*targs, _p(x), _p(y), _p(z), _p(m), _p(box), C.c_float(theta), _p(out),
+                             C.c_int(cap))
+    assert k <= cap
+    return out[:k].copy()
 
 
 def direct_f64(x, y, z, m, eps, gravity, t0=0, t1=None):

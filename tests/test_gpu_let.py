@@ -1,0 +1,180 @@
+"""Domain decomposition with a locally-essential-tree exchange, on one GPU: P (own, remote)
+handle pairs in one process play the P ranks, the exchange is a torch.cat.  Checked against
+the host oracle's independent top-down formulation of the export (bit-exact as a set), the
+oracle's traverse_from (float tolerance), a float64 direct sum and a single-handle run."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+import nbody_amd as nb
+from nbody_amd import parallel
+
+pytestmark = pytest.mark.gpu
+
+DOMAIN = 5.0
+
+
+def _params(n, bits, theta, eps=0.01, dt=1e-3):
+    return nb.Params(num_points=n, theta=theta, dt=dt, softening_factor=eps, morton_bits=bits,
+                     domain_size=DOMAIN)
+
+
+def _domains(ic, world, bits, theta, eps=0.01, dt=1e-3):
+    parts = parallel.domain_slices(ic["x"], ic["y"], ic["z"], world)
+    sims, bes = [], []
+    for idx in parts:
+        s = nb.Simulation(_params(len(idx), bits, theta, eps, dt))
+        s.set_state(ic["x"][idx], ic["y"][idx], ic["z"][idx], ic["m"][idx], ic["vx"][idx],
+                    ic["vy"][idx], ic["vz"][idx])
+        sims.append(s)
+        bes.append(parallel.GpuLetBackend(s, "cuda:0", record_capacity=64))  # forces a regrow
+    return parts, sims, bes
+
+
+def _emulated_step(bes):
+    """LetStepper.step() for all ranks of one process."""
+    W = len(bes)
+    for b in bes:
+        b.update()
+    boxes = np.stack([b.bbox() for b in bes])
+    recs = []
+    for r, b in enumerate(bes):
+        others = [q for q in range(W) if q != r]
+        out = b.let_export(boxes[others])
+        recs.append({q: t.clone() for q, t in zip(others, out)})
+    for r, b in enumerate(bes):
+        inc = [recs[q][r] for q in range(W) if q != r]
+        b.add_remote(torch.cat(inc) if inc else torch.empty(0, 4, device="cuda:0"))
+        b.finish_step()
+    return boxes, recs
+
+
+def _rows_sorted(a):
+    a = np.ascontiguousarray(a, np.float32).reshape(-1, 4)
+    return a[np.lexsort(a.T[::-1])]
+
+
+@pytest.mark.parametrize("kind,bits,world", [(nb.IC_SPHERE, 21, 2), (nb.IC_DISK, 21, 3),
+                                             (nb.IC_UNIFORM, 10, 4)])
+def test_let_export_equals_oracle(kind, bits, world):
+    n, theta = 6000, 0.6
+    ic = nb.sample_ic(kind, n, 11)
+    parts, sims, bes = _domains(ic, world, bits, theta)
+    boxes, recs = _emulated_step(bes)
+    for r, s in enumerate(sims):
+        st = s.get_state()
+        assert np.allclose(boxes[r][:3], [st[k].min() for k in "xyz"], rtol=0, atol=0)
+        assert np.allclose(boxes[r][3:], [st[k].max() for k in "xyz"], rtol=0, atol=0)
+        b = O.full_build(st["x"], st["y"], st["z"], st["m"], DOMAIN, bits, 32)
+        assert np.array_equal(b["xs"], st["x"])          # already in sorted order
+        for q in range(world):
+            if q == r:
+                continue
+            want = O.let_export(b["tree"], b["com"], b["xs"], b["ys"], b["zs"], b["ms"], boxes[q], theta)
+            got = recs[r][q].cpu().numpy()
+            assert got.shape == want.shape, (r, q, got.shape, want.shape)
+            assert np.array_equal(_rows_sorted(got), _rows_sorted(want))
+            assert 0 < len(got) < len(parts[r]) + b["tree"]["n_oct"]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_let_forces_match_direct_sum_and_single_domain(world):
+    n, theta, eps = 20000, 0.6, 0.01
+    ic = nb.sample_ic(nb.IC_SPHERE, n, 5)
+    parts, sims, bes = _domains(ic, world, 21, theta, eps)
+    _emulated_step(bes)
+    x, y, z, m, ax, ay, az = (np.empty(n, np.float32) for _ in range(7))
+    for idx, s in zip(parts, sims):
+        st = s.get_state()
+        g = idx[st["id"]]
+        x[g], y[g], z[g], m[g] = st["x"], st["y"], st["z"], st["m"]
+        ax[g], ay[g], az[g] = st["ax"], st["ay"], st["az"]
+    ref = O.direct_f64(x, y, z, m, eps, 1.0)
+    mean_let, max_let = O.acc_error(ax, ay, az, *ref)
+    one = nb.Simulation(_params(n, 21, theta, eps))
+    one.set_state(ic["x"], ic["y"], ic["z"], ic["m"], ic["vx"], ic["vy"], ic["vz"])
+    one.update()
+    s1 = one.get_state()
+    p = s1["id"]
+    assert np.array_equal(s1["x"], x[p])                  # same drift, same positions
+    mean_one, max_one = O.acc_error(s1["ax"], s1["ay"], s1["az"], *[r[p] for r in ref])
+    # the box criterion is more conservative than the per-group one: never much worse
+    assert mean_let < 1.5 * mean_one and mean_let < 1e-2, (mean_let, mean_one)
+    assert max_let < 3 * max_one + 5e-2, (max_let, max_one)
+
+
+def test_traverse_from_matches_oracle():
+    """Bodies of one handle against the tree of another: exact list lengths, float tolerance."""
+    n, theta, eps = 5000, 0.5, 0.01
+    ic = nb.sample_ic(nb.IC_SPHERE, 2 * n, 3)
+    a = nb.Simulation(_params(n, 21, theta, eps))
+    b = nb.Simulation(_params(n, 21, theta, eps))
+    half = lambda k, h: ic[k][h * n:(h + 1) * n]
+    # shift the second set so that part of it is far away (approximated nodes) and part overlaps
+    a.set_state(half("x", 0), half("y", 0), half("z", 0), half("m", 0))
+    b.set_state(half("x", 1) + np.float32(0.4), half("y", 1), half("z", 1), half("m", 1))
+    a.traverse_from(b, accumulate=False)
+    sa, sb = a.get_state(), b.get_state()
+    ll = a.get_octree()["list_len"]
+    tb = O.full_build(sb["x"], sb["y"], sb["z"], sb["m"], DOMAIN, 21, 32)
+    wx, wy, wz, wl = O.traverse_from((sa["x"], sa["y"], sa["z"]), tb["tree"], tb["com"], tb["xs"],
+                                     tb["ys"], tb["zs"], tb["ms"], 64, theta, eps, 1.0, DOMAIN)
+    assert np.array_equal(ll, wl)
+    for got, want in zip((sa["ax"], sa["ay"], sa["az"]), (wx, wy, wz)):
+        scale = np.sqrt(wx.astype(np.float64) ** 2 + wy ** 2 + wz ** 2)
+        assert np.max(np.abs(got - want) / scale) < 1e-4
+    # accumulate: a second pass doubles the result
+    a.traverse_from(b, accumulate=True)
+    s2 = a.get_state()
+    assert np.allclose(s2["ax"], 2 * sa["ax"], rtol=1e-6)
+
+
+def test_let_run_tracks_single_domain_run():
+    n, theta, steps = 8192, 0.5, 5
+    ic = nb.sample_ic(nb.IC_DISK, n, 9)
+    parts, sims, bes = _domains(ic, 3, 21, theta, 0.05, 1e-3)
+    one = nb.Simulation(_params(n, 21, theta, 0.05, 1e-3))
+    one.set_state(ic["x"], ic["y"], ic["z"], ic["m"], ic["vx"], ic["vy"], ic["vz"])
+    for _ in range(steps):
+        _emulated_step(bes)
+        one.update()
+    s1 = one.get_state()
+    inv = np.empty(n, np.int64)
+    inv[s1["id"]] = np.arange(n)
+    for idx, s in zip(parts, sims):
+        st = s.get_state()
+        g = inv[idx[st["id"]]]
+        for k in ("x", "y", "z"):
+            assert np.max(np.abs(st[k] - s1[k][g])) < 1e-5
+        for k in ("vx", "vy", "vz"):
+            assert np.max(np.abs(st[k] - s1[k][g])) < 2e-3 * np.max(np.abs(s1[k]))
+
+
+def test_source_handle_shrinks_and_grows():
+    """set_sources_dev with 0, 1, 3 and capacity records; the tree follows."""
+    cap = 3000
+    h = nb.Simulation(_params(cap, 21, 0.5))
+    body = nb.Simulation(_params(64, 21, 0.5))
+    ic = nb.sample_ic(nb.IC_UNIFORM, 64, 1)
+    body.set_state(ic["x"], ic["y"], ic["z"], ic["m"])
+    src = nb.sample_ic(nb.IC_UNIFORM, cap, 2)
+    posm = np.stack([src["x"] + np.float32(1.0), src["y"], src["z"], src["m"]], 1).astype(np.float32)
+    dev = torch.from_numpy(posm).cuda()
+    torch.cuda.synchronize()
+    for cnt in (cap, 1, 0, 3, cap):
+        h.set_sources_dev(dev.data_ptr(), cnt)
+        body.traverse_from(h, accumulate=False)
+        st = body.get_state()
+        both = np.concatenate([np.stack([st["x"], st["y"], st["z"], np.zeros(64, np.float32)], 1),
+                               posm[:cnt]])
+        ref = O.direct_f64(both[:, 0], both[:, 1], both[:, 2], both[:, 3], 0.01, 1.0, 0, 64)
+        if cnt == 0:
+            assert not st["ax"].any() and not st["ay"].any()
+        else:
+            mean, mx = O.acc_error(st["ax"], st["ay"], st["az"], *ref)
+            assert mx < 2e-2, (cnt, mx)
+            if cnt <= 32:   # a single leaf: direct, float32 rounding only
+                assert mx < 1e-5
+    with pytest.raises(RuntimeError):
+        h.set_sources_dev(dev.data_ptr(), cap + 1)

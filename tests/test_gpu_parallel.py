@@ -5,6 +5,7 @@ import os
 import re
 import socket
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -77,3 +78,71 @@ def test_ring_direct_sum_single_rank_gpu(single_rank_group):
     kern(posm, posm, True)
     torch.cuda.synchronize()
     assert np.allclose(out[0].cpu().numpy(), 2 * rx, rtol=1e-4, atol=1e-6)
+
+
+def test_let_stepper_single_rank_is_a_plain_step(single_rank_group):
+    """world = 1: no boxes, no records; the RCCL calls run with empty payloads."""
+    n = 8192
+    ic = nb.sample_ic(nb.IC_DISK, n, 3)
+    kw = dict(num_points=n, morton_bits=21, theta=0.5, dt=1e-3, softening_factor=0.01, device_id=0)
+    with nb.Simulation(nb.Params(**kw)) as a, nb.Simulation(nb.Params(**kw)) as b:
+        for s in (a, b):
+            s.set_state(ic["x"], ic["y"], ic["z"], ic["m"], ic["vx"], ic["vy"], ic["vz"])
+        st = parallel.LetStepper(parallel.GpuLetBackend(b, "cuda:0"))
+        for _ in range(3):
+            a.update()
+            st.step()
+        sa, sb = a.get_state(), b.get_state()
+    for k in ("x", "vx", "vy", "vz", "ax", "ay", "az"):
+        assert np.array_equal(sa[k], sb[k]), k
+
+
+_LET_WORKER = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import nbody_amd as nb
+from nbody_amd import parallel
+rank, world, n = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(sys.argv[2])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+ic = nb.sample_ic(nb.IC_SPHERE, n, 5)
+idx = parallel.domain_slices(ic["x"], ic["y"], ic["z"], world)[rank]
+sim = nb.Simulation(nb.Params(num_points=len(idx), morton_bits=21, theta=0.6, dt=1e-3,
+                              softening_factor=0.01, device_id=0))
+sim.set_state(*[ic[k][idx] for k in ("x", "y", "z", "m", "vx", "vy", "vz")])
+st = parallel.LetStepper(parallel.GpuLetBackend(sim, "cuda:0", exchange_device="cpu"))
+for _ in range(2):
+    st.step()
+s = sim.get_state()
+np.savez(sys.argv[3] + f"/rank{rank}.npz", gid=idx[s["id"]], sent=st.last_sent,
+         **{k: s[k] for k in ("x", "y", "z", "m", "ax", "ay", "az")})
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_let_stepper_two_processes_share_the_gpu(tmp_path):
+    """Two ranks (two processes, both on this GPU, records exchanged over gloo) run the real
+    GpuLetBackend; forces checked against a float64 direct sum over all particles."""
+    n, world = 12000, 2
+    script = tmp_path / "worker.py"
+    script.write_text(_LET_WORKER)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(n), str(tmp_path)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                      text=True))
+    for p in procs:
+        out, _ = p.communicate(timeout=110)
+        assert p.returncode == 0, out
+    full = {k: np.empty(n, np.float32) for k in ("x", "y", "z", "m", "ax", "ay", "az")}
+    for r in range(world):
+        d = np.load(tmp_path / f"rank{r}.npz")
+        assert 0 < int(d["sent"]) <= n // world
+        for k in full:
+            full[k][d["gid"]] = d[k]
+    ref = O.direct_f64(full["x"], full["y"], full["z"], full["m"], 0.01, 1.0)
+    mean, mx = O.acc_error(full["ax"], full["ay"], full["az"], *ref)
+    assert mean < 1e-2 and mx < 0.3, (mean, mx)
