@@ -11,9 +11,14 @@ input is resident in HBM when timing starts.
     python bench.py --gpus N --steps K --warmup W
 
 N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): weak scaling with
-2,097,152 particles per GPU.  Every rank holds the whole particle set and builds the same
-tree; the traversal -- the dominant cost -- is sharded by Morton-contiguous group ranges and
-the accelerations are exchanged with one all-gather per step.
+2,097,152 particles per GPU, i.e. one sphere of N x 2,097,152 particles.
+  --parallelism let (default): domain decomposition.  Every rank owns one box of an
+      orthogonal recursive bisection, builds and traverses its own tree, and imports a
+      locally-essential tree from the others (all-gather of boxes + one all-to-all of
+      (x,y,z,m) records per step).
+  --parallelism replicated: every rank holds the whole particle set and builds the same
+      tree; the traversal is sharded by Morton-contiguous group ranges and the
+      accelerations are exchanged with one all-gather per step (bit-identical to 1 GPU).
 
 Rank 0 prints ONE JSON line.
 """
@@ -137,7 +142,12 @@ def main():
     ap.add_argument("--no-alt-bits", action="store_true",
                     help="skip the short extra run with the other key width")
     ap.add_argument("--particles-per-gpu", type=int, default=N_PER_GPU)
+    ap.add_argument("--parallelism", choices=["let", "replicated"], default="let",
+                    help="multi-GPU scheme (ignored with one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="development aid: all ranks share GPU 0 and talk over gloo (the numbers "
+                         "mean nothing; it exercises the multi-rank code path on a 1-GPU box)")
     ap.add_argument("--walk-only", action="store_true",
                     help="profiling aid: skip the force arithmetic (results meaningless)")
     args = ap.parse_args()
@@ -157,12 +167,19 @@ def main():
     if not torch.cuda.is_available():
         sys.stderr.write("bench.py needs a GPU (no CPU fallback)\n")
         sys.exit(2)
+    rehearse = args.rehearse_on_one_gpu
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    coll_dev = "cpu" if rehearse else f"cuda:{local_rank}"
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     if args.workload == "direct":
         run_direct(args, world, rank, local_rank)
@@ -171,9 +188,16 @@ def main():
     n = args.particles_per_gpu * world
     group = 64
     ngroups = (n + group - 1) // group
-    assert ngroups % world == 0, "groups must divide evenly over the ranks"
+    let = world > 1 and args.parallelism == "let"
     ic = nb.sample_ic(nb.IC_SPHERE, n, 42)
-    params = nb.Params(num_points=n, max_num_codes_per_leaf=32, traversal_group_size=group,
+    if let:
+        from nbody_amd import parallel
+        own = parallel.domain_slices(ic["x"], ic["y"], ic["z"], world)[rank]
+        ic = {k: v[own] for k, v in ic.items()}
+    else:
+        assert ngroups % world == 0, "groups must divide evenly over the ranks"
+    n_here = len(ic["x"])
+    params = nb.Params(num_points=n_here, max_num_codes_per_leaf=32, traversal_group_size=group,
                        theta=THETA, dt=DT, gravity=1.0, softening_factor=EPS, domain_size=5.0,
                        morton_bits=args.morton_bits, device_id=local_rank,
                        flags=nb.FLAG_TIMING | (nb.FLAG_DEBUG_WALK_ONLY if args.walk_only else 0))
@@ -182,7 +206,10 @@ def main():
     U, M, n_oct = sim.tree_counts()
 
     stepper = None
-    if world > 1:
+    if let:
+        stepper = parallel.LetStepper(parallel.GpuLetBackend(
+            sim, f"cuda:{local_rank}", exchange_device="cpu" if rehearse else None))
+    elif world > 1:
         from nbody_amd import parallel
         stepper = parallel.ShardedTraversal(parallel.GpuBackend(sim, f"cuda:{local_rank}"))
 
@@ -220,10 +247,10 @@ def main():
     for k in tim:
         tim[k] += t[k]
     if world > 1:
-        red = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        red = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(red, op=dist.ReduceOp.MAX)
         elapsed = float(red.item())
-        it = torch.tensor([tim["interactions"]], dtype=torch.int64, device=f"cuda:{local_rank}")
+        it = torch.tensor([tim["interactions"]], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(it, op=dist.ReduceOp.SUM)
         total_inter = int(it.item())
     else:
@@ -265,7 +292,7 @@ def main():
         build_ms = (tim["ms_integrate"] + tim["ms_sort"] + tim["ms_build"] + tim["ms_com"]) / K
         inter_step_rank0 = tim["interactions"] / K
         tflops = FLOP_PER_INTERACTION * inter_step_rank0 / (trav_ms * 1e-3) / 1e12 if trav_ms else 0.0
-        build_gbs = BUILD_BYTES_PER_PARTICLE * n / (build_ms * 1e-3) / 1e9 if build_ms else 0.0
+        build_gbs = BUILD_BYTES_PER_PARTICLE * n_here / (build_ms * 1e-3) / 1e9 if build_ms else 0.0
         out = {
             "metric": "ms/step (build+traversal) at 2M particles theta=0.6",
             "value": round(ms_step, 4),
@@ -284,8 +311,10 @@ def main():
                                    "dt=1e-6, 32 codes/leaf, group=64",
                        "particles": n, "morton_bits": args.morton_bits,
                        "parallelism": "single" if world == 1 else
-                       f"replicated build, traversal sharded over {world} Morton ranges, "
-                       "all-gather of accelerations",
+                       (f"{world} domains (orthogonal recursive bisection), own tree per GPU, "
+                        "locally-essential-tree exchange (all-to-all of records)" if let else
+                        f"replicated build, traversal sharded over {world} Morton ranges, "
+                        "all-gather of accelerations"),
                        "tree": {"unique_codes": U, "leaves": M, "octree_nodes": n_oct}},
             "build_ms": round(build_ms, 4),
             "traversal_ms": round(trav_ms, 4),
@@ -307,6 +336,15 @@ def main():
                                "unit": "GB/s", "frac": round(build_gbs / PEAK_HBM_GBS, 4),
                                "note": "300 algorithmic B/particle over integrate+sort+build+COM"},
         }
+        if let:
+            # the traversals run outside nbody_update() in this mode: no per-kernel figures
+            for k in ("traversal_ms", "interactions_per_step", "interactions_per_s"):
+                out[k] = None
+            out["stage_ms"]["traverse"] = None
+            out["roofline"].update(achieved=None, frac=None,
+                                   note="per-kernel figures are reported by the 1-GPU run")
+            out["let_records_per_step"] = {"sent_rank0": stepper.last_sent,
+                                           "received_rank0": stepper.last_received}
         if alt is not None:
             out["other_key_width"] = alt
         if world == 1 and not args.no_cpu_baseline:

@@ -94,10 +94,12 @@ class ShardedTraversal:
 
 class LetStepper:
     """backend must provide:
-        update()                      kick-drift, sort, build, own-tree traversal (kick deferred)
+        update()                      kick-drift, sort, build of the own tree (no forces yet)
         bbox()                        6 floats (lo xyz, hi xyz) of the own particles
         let_export(boxes)             boxes: (k, 6) float32 array -> list of k (cnt_i, 4)
                                       float32 torch tensors on the backend's device
+        begin_local_forces()          start the own-tree traversal; may return before it is
+                                      done, so that it runs while the records are exchanged
         add_remote(records)           (cnt, 4) tensor: build a tree over it, add its attraction
         finish_step()                 velocity kick
         device                        torch device of the exchanged tensors
@@ -121,6 +123,7 @@ class LetStepper:
         boxes = boxes.view(W, 6)
         others = [r for r in range(W) if r != me]
         recs = b.let_export(boxes.cpu().numpy()[others]) if others else []
+        b.begin_local_forces()
         send_rows = [0] * W
         for r, t in zip(others, recs):
             send_rows[r] = int(t.shape[0])
@@ -245,7 +248,7 @@ class GpuLetBackend:
         self.device = torch.device(exchange_device) if exchange_device else self.gpu
         self.n = sim.params.num_points
         g = sim.params.traversal_group_size
-        sim.set_traversal_range(0, (self.n + g - 1) // g)   # defer the kick to finish_step()
+        sim.set_traversal_range(0, 0)   # update() = build only; forces and kick are driven here
         self.cap = int(record_capacity or max(4096, self.n // 4))
         self._buf = None
         self.remote = None
@@ -269,6 +272,9 @@ class GpuLetBackend:
                 self.cap = int(max(e.counts) * 1.25) + 1024
                 self._buf = None
         return [self._buf[i, :int(c)].to(self.device) for i, c in enumerate(counts)]
+
+    def begin_local_forces(self):
+        self.sim.traverse_from(self.sim, accumulate=False)   # queued, not waited for
 
     def add_remote(self, records):
         cnt = int(records.shape[0])

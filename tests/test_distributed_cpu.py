@@ -174,6 +174,10 @@ class OracleLetBackend:
         self.vh = [h[p] for h in vh]
         self.gid = self.gid[p]
         self.tree = b
+        self.acc = None
+
+    def begin_local_forces(self):
+        b = self.tree
         ax, ay, az, _ = O.traverse(b["tree"], b["com"], self.x, self.y, self.z, self.m, self.group,
                                    self.theta, self.eps, 1.0, 5.0)
         self.acc = [ax, ay, az]
@@ -249,6 +253,7 @@ def test_let_stepper_tracks_single_rank_and_direct_sum(world, n):
     one = OracleLetBackend(ic, np.arange(n), 64, 0.5, 1e-3, 0.01, 21)
     for _ in range(3):
         one.update()
+        one.begin_local_forces()
         one.finish_step()
     assert np.array_equal(np.sort(one.x), np.sort(ref.x))   # world=1 LET == plain stepper
     ox = np.empty(n, np.float32); ox[one.gid] = one.x

@@ -43,6 +43,7 @@ def _emulated_step(bes):
         others = [q for q in range(W) if q != r]
         out = b.let_export(boxes[others])
         recs.append({q: t.clone() for q, t in zip(others, out)})
+        b.begin_local_forces()
     for r, b in enumerate(bes):
         inc = [recs[q][r] for q in range(W) if q != r]
         b.add_remote(torch.cat(inc) if inc else torch.empty(0, 4, device="cuda:0"))
