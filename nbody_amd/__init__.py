@@ -15,7 +15,7 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnbody_mi355.so")
+LIB_PATH = os.environ.get("NBODY_AMD_LIB") or os.path.join(_HERE, "libnbody_mi355.so")
 
 OK = 0
 ERR_CAPACITY = 6

@@ -30,6 +30,7 @@
 //     instruction, v_rsq_f32 once per source.
 // The set of sources a group interacts with does not depend on the order candidates are
 // visited in, so list lengths equal those of the reference's breadth-first walk.
+#include <cstdio>
 #include "dev_utils.hpp"
 #include "nbody_internal.hpp"
 
@@ -40,9 +41,23 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v8f __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
+// Development aid, off in the shipped library: -DNB_WALK_PROFILE=1 makes every wave add the
+// shader-clock cycles it spends in each phase to g_walk_prof and the launcher print the sums.
+#ifndef NB_WALK_PROFILE
+#define NB_WALK_PROFILE 0
+#endif
+#if NB_WALK_PROFILE
+__device__ unsigned long long g_walk_prof[8];
+#define PROF_T0() const long long t0_ = clock64()
+#define PROF_ADD(slot) do { if (lane == 0) prof_acc[slot] += clock64() - t0_; } while (0)
+#else
+#define PROF_T0() do {} while (0)
+#define PROF_ADD(slot) do {} while (0)
+#endif
+
 constexpr int TRAV_RESERVE = 7 * 24;  // single-pop fallback never needs more than 7/level
 
-// Per-wave LDS working set (7936 B).  Bodies and sources are stored as PAIRS,
+// Per-wave LDS working set (7936 B with the sizes in nbody_internal.hpp).  Bodies and sources are stored as PAIRS,
 // (x0,x1,y0,y1) and (z0,z1[,m0,m1]), so that one 64-bit register pair feeds one packed op.
 struct alignas(16) WaveLds {
     v4f bxy[32];
@@ -51,6 +66,7 @@ struct alignas(16) WaveLds {
     v4f lzm[64];
     int stack[TRAV_STACK];
     int leaf[TRAV_LEAF_STACK];
+    int pend[TRAV_PEND];   // candidates waiting for the exact distance test
 };
 
 template <int G, bool FUSE_VEL, bool WALK_ONLY>
@@ -81,6 +97,10 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
         bxyf[4 * p + 2 + h] = me.y;
         bzf[2 * p + h] = me.z;
     }
+#if NB_WALK_PROFILE
+    long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long t_begin = clock64();
+#endif
     int sp = 0, leaf_n = 0;
     {
         const bool root_leaf = (nodeB[0].meta & NODE_LEAF) != 0u;
@@ -120,6 +140,7 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
         lzmf[4 * p + 2 + h] = v.w;
     };
     auto flush64 = [&]() {
+        PROF_T0();
         __builtin_amdgcn_wave_barrier();
         const int hp = head >> 1;
 #pragma unroll 8
@@ -127,6 +148,7 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
         head ^= 64;
         list_n -= 64;
         __builtin_amdgcn_wave_barrier();
+        PROF_ADD(2);
     };
 
     // Sources of one pair record held in SGPRs (wave-uniform): no LDS, no VGPR staging.
@@ -169,6 +191,7 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
         append_particles(is_tail && (pe & 1), pe - 1);
         // whole pairs of every run -> scalar path
         unsigned long long hm = __ballot(is_head);
+        PROF_T0();
         while (hm) {
             const int h = (int) __builtin_ctzll(hm);
             hm &= hm - 1;
@@ -184,14 +207,20 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
                 const v16f *P16 = reinterpret_cast<const v16f *>(posm2);
                 const int d1 = q1 >> 1;
                 int d = q0 >> 1;
+                // Scalar loads return out of order, so the only wait there is, is "all of them":
+                // wait for the record about to be used BEFORE requesting the next one, or the
+                // wait the compiler places ahead of the first use would cover the new request
+                // too and the prefetch would hide nothing.
                 v16f ra = P16[d], rb2;
                 while (true) {
                     const bool hb = d + 1 < d1;
+                    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): ra has arrived
                     if (hb) rb2 = P16[d + 1];
                     pair_force_s(ra.lo);
                     pair_force_s(ra.hi);
                     if (!hb) break;
                     const bool ha = d + 2 < d1;
+                    __builtin_amdgcn_s_waitcnt(0xC07F);   // rb2 has arrived
                     if (ha) ra = P16[d + 2];
                     pair_force_s(rb2.lo);
                     pair_force_s(rb2.hi);
@@ -202,26 +231,37 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
             }
             if (q0 < q1) pair_force_s(posm2[q0]);
         }
+        PROF_ADD(1);
     };
 
-    while (true) {
-        while (leaf_n >= 64 || (sp == 0 && leaf_n > 0)) process_leaves();
-        if (sp == 0) break;
-
-        const int room = TRAV_STACK - TRAV_RESERVE - sp;
-        // leaf_n < 64 here; every popped node may add up to 8 leaves
-        const int k = min(min(min(sp, 64), max(room / 7, 1)), (TRAV_LEAF_STACK - leaf_n) >> 3);
-        const bool valid = lane < k;
-        const int node = valid ? L.stack[sp - k + lane] : 0;
-        sp -= k;
-        const Float4 A = nodeA[node];
-        const NodeB B = nodeB[node];
-
-        // d2min over the group's bodies, two per packed instruction
+    // Bounding box of the group's bodies and four sample body pairs: most candidates are
+    // decided from these alone, with the SAME outcome as the exact test below --
+    //   * the distance from the box to the centre of mass, computed with the same operation
+    //     sequence as a body's distance, is <= every body's computed distance (each step is
+    //     monotone under rounding), so  size^2/d_box^2 < theta^2  implies acceptance;
+    //   * a sample body's computed distance is one of the terms of the exact minimum, so
+    //     !(size^2/d_sample^2 < theta^2)  implies the node is opened.
+    // Only the undecided rest is queued (L.pend) for the exact 64-body minimum, which is run
+    // 32 candidates at a time with two lanes per candidate.
+    float blo[3] = {me.x, me.y, me.z}, bhi[3] = {me.x, me.y, me.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            blo[a] = fminf(blo[a], __shfl_xor(blo[a], o, 64));
+            bhi[a] = fmaxf(bhi[a], __shfl_xor(bhi[a], o, 64));
+        }
+        // wave-uniform from here on: keep the box in scalar registers
+        blo[a] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, blo[a])));
+        bhi[a] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, bhi[a])));
+    }
+    int pend_n = 0;
+    // exact d2min of this lane's candidate over the body pairs part, part+nparts, ...
+    auto exact_dmin = [&](const Float4 A, int part, int nparts) -> float {
         const v2f ax2 = {A.x, A.x}, ay2 = {A.y, A.y}, az2 = {A.z, A.z};
         float dmin = dinit;
 #pragma unroll 4
-        for (int j = 0; j < G / 2; ++j) {
+        for (int j = part; j < G / 2; j += nparts) {
             const v4f q = L.bxy[j];
             const v2f qz = L.bz[j];
             const v2f dx = q.xy - ax2, dy = q.zw - ay2, dz = qz - az2;
@@ -229,7 +269,70 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
                 dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
             dmin = fminf(dmin, fminf(d.x, d.y));
         }
-        const bool approx = valid && (__fdiv_rn(B.size * B.size, dmin) < th2);
+        return dmin;
+    };
+
+    while (true) {
+        while (leaf_n >= 64 || (sp == 0 && pend_n == 0 && leaf_n > 0)) process_leaves();
+        if (sp == 0 && pend_n == 0) break;
+
+        PROF_T0();
+        const int room = TRAV_STACK - TRAV_RESERVE - sp;
+        const int leaf_room = (TRAV_LEAF_STACK - leaf_n) >> 3;   // a node adds up to 8 leaves
+        bool valid, approx;
+        Float4 A;
+        NodeB B;
+        // undecided candidates first once 32 have gathered (or nothing else is left), as long
+        // as their children are sure to fit
+        const int kx = (pend_n >= 32 || sp == 0) ? min(min(pend_n, 32), min(room / 7, leaf_room)) : 0;
+        if (kx > 0) {
+            const int slot = lane & 31;
+            const bool have = slot < kx;
+            const int node = have ? L.pend[pend_n - kx + slot] : 0;
+            pend_n -= kx;
+            A = nodeA[node];
+            B = nodeB[node];
+            float dmin = exact_dmin(A, lane >> 5, 2);
+            dmin = fminf(dmin, __shfl_xor(dmin, 32, 64));
+            valid = have && lane < 32;
+            approx = valid && (__fdiv_rn(B.size * B.size, dmin) < th2);
+        } else {
+            // leaf_n < 64 here
+            const int k = min(min(min(sp, 64), max(room / 7, 1)), leaf_room);
+            valid = lane < k;
+            const int node = valid ? L.stack[sp - k + lane] : 0;
+            sp -= k;
+            A = nodeA[node];
+            B = nodeB[node];
+            const float sz2 = B.size * B.size;
+            if (pend_n + k <= TRAV_PEND) {
+                const float ex = fmaxf(0.f, fmaxf(blo[0] - A.x, A.x - bhi[0]));
+                const float ey = fmaxf(0.f, fmaxf(blo[1] - A.y, A.y - bhi[1]));
+                const float ez = fmaxf(0.f, fmaxf(blo[2] - A.z, A.z - bhi[2]));
+                const float dbox = fminf(dinit, fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
+                approx = valid && (__fdiv_rn(sz2, dbox) < th2);
+                const v2f ax2 = {A.x, A.x}, ay2 = {A.y, A.y}, az2 = {A.z, A.z};
+                float ds = dinit;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int jj = t == 3 ? G / 2 - 1 : t * (G / 6);
+                    const v4f q = L.bxy[jj];
+                    const v2f qz = L.bz[jj];
+                    const v2f dx = q.xy - ax2, dy = q.zw - ay2, dz = qz - az2;
+                    const v2f d = __builtin_elementwise_fma(
+                        dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                    ds = fminf(ds, fminf(d.x, d.y));
+                }
+                const bool sure_open = !(__fdiv_rn(sz2, ds) < th2);
+                const bool undecided = valid && !approx && !sure_open;
+                const unsigned long long um = __ballot(undecided);
+                if (undecided) L.pend[pend_n + mbcnt(um)] = node;
+                pend_n += (int) __popcll(um);
+                valid = valid && !undecided;
+            } else {   // no room to defer anything: exact test for every candidate of the round
+                approx = valid && (__fdiv_rn(sz2, exact_dmin(A, 0, 1)) < th2);
+            }
+        }
         const bool open = valid && !approx;
 
         // accepted nodes -> source ring
@@ -260,6 +363,10 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
         sp += tot_i;
         leaf_n += tot_l;
         __builtin_amdgcn_wave_barrier();
+        PROF_ADD(0);
+#if NB_WALK_PROFILE
+        if (lane == 0) prof_acc[4] += 1;
+#endif
 
         if (list_n >= 64) flush64();
     }
@@ -276,6 +383,12 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
     }
     const float fx = fx2.x + fx2.y, fy = fy2.x + fy2.y, fz = fz2.x + fz2.y;
 
+#if NB_WALK_PROFILE
+    if (lane == 0) {
+        prof_acc[3] = clock64() - t_begin;
+        for (int i = 0; i < 5; ++i) atomicAdd(&g_walk_prof[i], (unsigned long long) prof_acc[i]);
+    }
+#endif
     if (lane == 0) tail->list_len[g] = total;
     if (active) {
         float axv = gravity * fx, ayv = gravity * fy, azv = gravity * fz;
@@ -413,6 +526,17 @@ static hipError_t traverse_impl(Sim *s, Sim *src, bool fuse_vel, int acc_flag)
             if (fuse_vel) NB_TRAV(32, true, false); else NB_TRAV(32, false, false);
         }
 #undef NB_TRAV
+#if NB_WALK_PROFILE
+        (void) hipStreamSynchronize(s->stream);
+        unsigned long long h[8], z[8] = {0};
+        (void) hipMemcpyFromSymbol(h, HIP_SYMBOL(g_walk_prof), sizeof h);
+        (void) hipMemcpyToSymbol(HIP_SYMBOL(g_walk_prof), z, sizeof z);
+        const double tot = (double) h[3];
+        fprintf(stderr, "walk profile: groups %d  MAC rounds/group %.1f  wave-cycles/group %.0f | "
+                        "MAC+push %.1f%%  leaf runs (scalar path) %.1f%%  ring flush %.1f%%  other %.1f%%\n",
+                g1 - g0, (double) h[4] / (g1 - g0), tot / (g1 - g0), 100.0 * h[0] / tot,
+                100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * (tot - h[0] - h[1] - h[2]) / tot);
+#endif
     }
     return hipGetLastError();
 }

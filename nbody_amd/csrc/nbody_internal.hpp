@@ -19,7 +19,8 @@ constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 constexpr int LET_MAX_BOXES = 256;
 constexpr int TRAV_WAVES = 4;                       // groups (waves) per traversal workgroup
 constexpr int TRAV_STACK = 512;                     // LDS inner-node stack entries per wave
-constexpr int TRAV_LEAF_STACK = 640;                // LDS leaf stack entries per wave
+constexpr int TRAV_LEAF_STACK = 544;                // LDS leaf stack entries per wave
+constexpr int TRAV_PEND = 96;                       // LDS queue of candidates awaiting the exact test
 constexpr int MAX_DEPTH_BINS = 256;                 // depth key space of the node ranking pass
 constexpr int TIMING_RING = 64;
 enum { EV_BEGIN = 0, EV_INTEGRATE, EV_SORT, EV_BUILD, EV_COM, EV_TRAVERSE, EV_COUNT };
