@@ -82,8 +82,10 @@ int alloc_all(Sim *s)
     }
     NB_HIP(s, dalloc(&s->ax, n)); NB_HIP(s, dalloc(&s->ay, n)); NB_HIP(s, dalloc(&s->az, n));
     NB_HIP(s, dalloc(&s->posm, n));
-    NB_HIP(s, dalloc(&s->posm2, 8 * ((n + 1) / 2)));
-    NB_HIP(s, hipMemsetAsync(s->posm2, 0, 8 * ((n + 1) / 2) * 4, s->stream));
+    // pair records are read two at a time (64 bytes): pad to a whole number of those
+    const size_t posm2_floats = 16 * ((n + 3) / 4);
+    NB_HIP(s, dalloc(&s->posm2, posm2_floats));
+    NB_HIP(s, hipMemsetAsync(s->posm2, 0, posm2_floats * 4, s->stream));
 
     // sort scratch: ghist[8*256] | tickets[16] | status[P][tiles][256]
     s->sort_tiles = (int) ((n + SORT_TILE - 1) / SORT_TILE);

@@ -186,6 +186,18 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
         const int next_pb = __shfl_down(pb, 1, 64);
         const bool is_head = valid && (lane == 0 || prev_end != pb);
         const bool is_tail = valid && (lane == cnt - 1 || next_pb != pe);
+        // The scalar stream below has one request in flight per wave, so a miss in L2 stalls
+        // it for a full memory round trip.  Touch every 128-byte line of this lane's leaf with
+        // an ordinary vector load first: all 64 leaves of the batch are then on their way into
+        // L2 at once, long before the stream reaches them.  The values are not used.
+        float touch[4];
+        {
+            const char *lb = reinterpret_cast<const char *>(posm2) + (size_t) (pb >> 1) * 32;
+            const int bytes = valid ? (((pe + 1) >> 1) - (pb >> 1)) * 32 : 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                touch[t] = t * 128 < bytes ? *reinterpret_cast<const float *>(lb + t * 128) : 0.f;
+        }
         // odd particle at either end of a run -> LDS list (two batched gathers per 64 leaves)
         append_particles(is_head && (pb & 1), pb);
         append_particles(is_tail && (pe & 1), pe - 1);
@@ -232,6 +244,7 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
             if (q0 < q1) pair_force_s(posm2[q0]);
         }
         PROF_ADD(1);
+        asm volatile("" ::"v"(touch[0]), "v"(touch[1]), "v"(touch[2]), "v"(touch[3]));
     };
 
     // Bounding box of the group's bodies and four sample body pairs: most candidates are

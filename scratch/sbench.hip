@@ -54,19 +54,18 @@ __global__ __launch_bounds__(256, 5) void k(const float *__restrict__ src, const
             size_t base = MODE == 1 ? 0 : ((size_t) gw * 977 + (size_t) r * 131) * 512 % (window - 512);
             const v16f *P = big + base;
             if (MODE == 5 || MODE == 6) {
-                // four register sets: two records in flight while two are consumed
-                v16f a = P[0], b = P[1], c, e;
-                for (int d = 0; d < 512; d += 4) {
+                // three register sets: every wait covers requests that were issued one and two
+                // record evaluations earlier
+                v16f a = P[0], b = P[1], c;
+                for (int d = 0; d < 510; d += 3) {
                     __builtin_amdgcn_s_waitcnt(0xC07F);      // a, b ready
                     c = P[d + 2];
                     pf8(a.lo); pf8(a.hi);
-                    e = P[d + 3];
+                    a = P[d + 3];
                     pf8(b.lo); pf8(b.hi);
-                    __builtin_amdgcn_s_waitcnt(0xC07F);      // c, e ready
-                    if (d + 4 < 512) a = P[d + 4];
+                    __builtin_amdgcn_s_waitcnt(0xC07F);      // c, a ready
+                    b = P[d + 4];
                     pf8(c.lo); pf8(c.hi);
-                    if (d + 4 < 512) b = P[d + 5];
-                    pf8(e.lo); pf8(e.hi);
                 }
             } else if (MODE == 3) {
                 for (int run = 0; run < 64; ++run) {   // 64 runs of 8 records
@@ -141,8 +140,8 @@ int main()
         run<2>("SGPR, streaming 64 MB", lds, src, big, recs, out);
         run<3>("SGPR, streaming, runs of 16 pairs", lds, src, big, recs, out);
         run<4>("SGPR, 2 MB window", lds, src, big, recs, out);
-        run<5>("SGPR, streaming, 4 sets", lds, src, big, recs, out);
-        run<6>("SGPR, 2 MB window, 4 sets", lds, src, big, recs, out);
+        run<5>("SGPR, streaming, 3 sets", lds, src, big, recs, out);
+        run<6>("SGPR, 2 MB window, 3 sets", lds, src, big, recs, out);
     }
     return 0;
 }
