@@ -6,6 +6,7 @@ import nbody_amd as nb
 from nbody_amd import parallel
 
 world = int(sys.argv[1]); n_per = int(sys.argv[2]); bits = int(sys.argv[3]) if len(sys.argv) > 3 else 21
+leafc = int(sys.argv[4]) if len(sys.argv) > 4 else 32
 n = world * n_per
 t0 = time.time()
 ic = nb.sample_ic(nb.IC_SPHERE, n, 42)
@@ -16,7 +17,7 @@ for idx in parts:
     s = nb.Simulation(nb.Params(num_points=len(idx), theta=0.6, dt=1e-6, softening_factor=0.1,
                                 morton_bits=bits, flags=nb.FLAG_TIMING))
     s.set_state(ic["x"][idx], ic["y"][idx], ic["z"][idx], ic["m"][idx])
-    sims.append(s); bes.append(parallel.GpuLetBackend(s, "cuda:0"))
+    sims.append(s); bes.append(parallel.GpuLetBackend(s, "cuda:0", remote_codes_per_leaf=leafc))
 print("created", flush=True)
 sync = torch.cuda.synchronize
 def tick():
