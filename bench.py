@@ -325,13 +325,22 @@ def main():
             "finite": ok,
             "baseline_note": "vs_baseline = ms/step / 150 ms (reference README, RTX 500 Ada "
                              "laptop GPU; different hardware)",
-            "roofline": {"bound": "valu", "kernel": "k_traverse", "achieved": round(tflops, 2),
+            "roofline": {"bound": "mfma", "kernel": "k_traverse", "achieved": round(tflops, 2),
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tflops / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
-                         "traffic_note": "HBM bytes per launch from the committed rocprofv3 PMC "
+                         "traffic_note": "HBM-side bytes per launch from the committed rocprofv3 PMC "
                                          "passes (profiles/r1_traffic.json), not measured in this run",
-                         "note": "20 FLOP x exact interaction count / mean kernel time (HIP "
-                                 "events on the library stream); FP32 vector peak, MFMA unused"},
+                         "pipe": "FP32 vector ALU (v_pk_fma_f32 / v_rsq_f32); priced against the dense "
+                                 "f32 peak, which is the same 157.3 TFLOP/s for MFMA and packed VALU",
+                         "note": "20 FLOP x exact interaction count / mean kernel time (HIP events on "
+                                 "the library stream)",
+                         "issue_bound": {"cycles_per_128_interactions": 64,
+                                         "peak_interactions_per_s": round(1024 * 2.4e9 * 2),
+                                         "achieved_interactions_per_s": round(inter_step_rank0 / (trav_ms * 1e-3)) if trav_ms else None,
+                                         "frac": round(inter_step_rank0 / (trav_ms * 1e-3) / (1024 * 2.4e9 * 2), 4) if trav_ms else None,
+                                         "note": "12 packed ops (4 cycles) + 2 v_rsq_f32 (8 cycles) per wave "
+                                                 "per two sources: the instruction-issue floor of the force "
+                                                 "arithmetic at 2.4 GHz on 1024 SIMDs"}},
             "roofline_build": {"bound": "hbm", "achieved": round(build_gbs, 1), "peak": PEAK_HBM_GBS,
                                "unit": "GB/s", "frac": round(build_gbs / PEAK_HBM_GBS, 4),
                                "note": "300 algorithmic B/particle over integrate+sort+build+COM"},

@@ -415,24 +415,25 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
     }
 }
 
-// sum over groups of list_len[g] * bodies_in_group(g) -> *out (u64), single workgroup.
+// *out (u64, zeroed by the launcher) += sum over groups of list_len[g] * bodies_in_group(g).
 __global__ __launch_bounds__(256) void k_count_interactions(int n, int group, int g0, int g1,
                                                             const uint32_t *__restrict__ list_len,
                                                             unsigned long long *out)
 {
-    __shared__ unsigned long long s[256];
+    __shared__ unsigned long long s[4];
     unsigned long long acc = 0;
-    for (int g = g0 + (int) threadIdx.x; g < g1; g += 256) {
+    for (int g = g0 + (int) (blockIdx.x * 256 + threadIdx.x); g < g1; g += (int) gridDim.x * 256) {
         const int nb = min(group, n - g * group);
         acc += (unsigned long long) list_len[g] * (unsigned long long) nb;
     }
-    s[threadIdx.x] = acc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int) threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = s[0] + s[1] + s[2] + s[3];
+        if (t) atomicAdd(out, t);
     }
-    if (threadIdx.x == 0) *out = s[0];
 }
 
 // ---------------------------------------------------------------------------
@@ -566,8 +567,11 @@ hipError_t launch_count_interactions(Sim *s, unsigned long long *out)
     const int ngroups = (s->n + s->group - 1) / s->group;
     const int g0 = s->trav_g1 < 0 ? 0 : s->trav_g0;
     const int g1 = s->trav_g1 < 0 ? ngroups : std::min(s->trav_g1, ngroups);
-    hipLaunchKernelGGL(k_count_interactions, dim3(1), dim3(256), 0, s->stream, s->n, s->group, g0,
-                       g1, s->list_len, out);
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(unsigned long long), s->stream);
+    if (e != hipSuccess) return e;
+    const int grid = std::max(1, std::min(64, (g1 - g0 + 255) / 256));
+    hipLaunchKernelGGL(k_count_interactions, dim3(grid), dim3(256), 0, s->stream, s->n, s->group,
+                       g0, g1, s->list_len, out);
     return hipGetLastError();
 }
 
