@@ -145,6 +145,10 @@ def main():
     ap.add_argument("--parallelism", choices=["let", "replicated"], default="let",
                     help="multi-GPU scheme (ignored with one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--evolve-steps", type=int, default=2000,
+                    help="1 GPU only: after the timed region advance this many more steps (the cold "
+                         "sphere collapses and rebounds within ~300) and time 20 steps of the "
+                         "clustered state, reported beside `value`; 0 = skip")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development aid: all ranks share GPU 0 and talk over gloo (the numbers "
                          "mean nothing; it exercises the multi-rank code path on a 1-GPU box)")
@@ -257,6 +261,29 @@ def main():
         total_inter = int(tim["interactions"])
     st = sim.get_state()
     ok = bool(np.isfinite(st["ax"]).all() and np.isfinite(st["x"]).all())
+    evolved = None
+    if world == 1 and args.evolve_steps > 0 and not args.walk_only:
+        left = args.evolve_steps
+        while left > 0:
+            k = min(left, 48)
+            sim.step(k)
+            sim.get_timings()
+            left -= k
+        sim.sync()
+        ta = time.perf_counter()
+        sim.step(20)
+        sim.sync()
+        tb = time.perf_counter()
+        t3 = sim.get_timings()
+        s3 = sim.get_state()
+        r = np.sqrt((s3["x"] - 2.5) ** 2 + (s3["y"] - 2.5) ** 2 + (s3["z"] - 2.5) ** 2)
+        evolved = {"after_steps": args.warmup + args.steps + args.evolve_steps,
+                   "ms_per_step": round((tb - ta) * 1e3 / 20, 4),
+                   "traversal_ms": round(t3["ms_traverse"] / 20, 4),
+                   "interactions_per_step": round(t3["interactions"] / 20),
+                   "half_mass_radius": round(float(np.median(r)), 4),
+                   "r99": round(float(np.quantile(r, 0.99)), 4),
+                   "finite": bool(np.isfinite(s3["ax"]).all() and np.isfinite(s3["x"]).all())}
     sim.close()
 
     alt = None
@@ -354,6 +381,8 @@ def main():
                                    note="per-kernel figures are reported by the 1-GPU run")
             out["let_records_per_step"] = {"sent_rank0": stepper.last_sent,
                                            "received_rank0": stepper.last_received}
+        if evolved is not None:
+            out["after_collapse"] = evolved
         if alt is not None:
             out["other_key_width"] = alt
         if world == 1 and not args.no_cpu_baseline:

@@ -75,6 +75,15 @@ void nbody_default_params(nbody_params *p);
  * Unlike the reference's headless constructor this one does install the physics
  * parameters (the reference only does so in the GL constructor, simulation.cu:67-72). */
 int nbody_create(const nbody_params *params, nbody_t **out);
+/* Simulation(Params&, GLuint buffers[7])  (reference: include/simulation.hpp:31,
+ * src/cuda/simulation.cu:39-51,138-158): the viewer-owned buffers
+ * [pos.x, pos.y, pos.z, com.x, com.y, com.z, node_size].  The reference maps seven GL buffers
+ * and uses them as storage; here dev_ptrs are seven caller-owned DEVICE pointers to float --
+ * the first three with room for num_points values, the last four for 2*num_points (one per
+ * octree node) -- into which the library copies the current positions (sorted order) and
+ * the octree nodes' centres of mass and sizes after every spawn/set_state/update, on the
+ * handle's stream.  NULL entries are skipped; dev_ptrs == NULL equals nbody_create. */
+int nbody_create_external(const nbody_params *params, void *dev_ptrs[7], nbody_t **out);
 /* ~Simulation() (include/simulation.hpp:38). */
 void nbody_destroy(nbody_t *sim);
 const char *nbody_last_error(nbody_t *sim);

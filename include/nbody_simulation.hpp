@@ -4,8 +4,9 @@
 // Same public surface as the reference (include/simulation.hpp:11-47): nested Params with
 // the same fields in the same order, Simulation(Params&), spawn_uniform(), spawn_sphere(),
 // spawn_disk(), update(), get_num_octree_nodes(), write_validation_history().  The GL
-// constructor Simulation(Params&, GLuint[7]) is not offered: the renderer is outside this
-// library; use device_view() to read the particle buffers in place instead.
+// constructor Simulation(Params&, GLuint[7]) becomes Simulation(Params&, void*[7]): seven
+// caller-owned device buffers that receive positions and octree centres of mass / sizes
+// after every update; device_view() reads the library's own buffers in place.
 // Errors, which the reference silently ignores, throw std::runtime_error.
 // Only T = float exists (the reference's shipped SIM_PRECISION, include/renderer.hpp:14).
 #ifndef NBODY_SIMULATION_HPP
@@ -40,6 +41,13 @@ public:
     // morton_bits: 10 (30-bit keys) or 21 (the reference's 63-bit keys).
     explicit Simulation(Params &params, int morton_bits = 21, int device_id = -1,
                         unsigned flags = 0)
+        : Simulation(params, nullptr, morton_bits, device_id, flags)
+    {
+    }
+    // buffers: [pos.x, pos.y, pos.z, com.x, com.y, com.z, node_size], device pointers to float
+    // (include/simulation.hpp:31); see nbody_create_external for sizes.
+    Simulation(Params &params, void *buffers[7], int morton_bits = 21, int device_id = -1,
+               unsigned flags = 0)
         : params_(params)
     {
         nbody_params p;
@@ -58,7 +66,7 @@ public:
         p.morton_bits = morton_bits;
         p.device_id = device_id;
         p.flags = flags;
-        const int rc = nbody_create(&p, &sim_);
+        const int rc = nbody_create_external(&p, buffers, &sim_);
         if (rc != NBODY_OK) throw std::runtime_error("nbody_create failed, status " + std::to_string(rc));
     }
     Simulation(const Simulation &) = delete;

@@ -74,7 +74,7 @@ class CTimings(C.Structure):
 
 
 EXPORTS = [
-    "nbody_default_params", "nbody_create", "nbody_destroy", "nbody_last_error",
+    "nbody_default_params", "nbody_create", "nbody_create_external", "nbody_destroy", "nbody_last_error",
     "nbody_spawn_uniform", "nbody_spawn_sphere", "nbody_spawn_disk", "nbody_spawn_plummer",
     "nbody_sample_ic", "nbody_set_state", "nbody_update", "nbody_step", "nbody_sync",
     "nbody_get_num_octree_nodes", "nbody_write_validation_history", "nbody_get_state",
@@ -96,11 +96,20 @@ def load_library() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `make -C nbody_amd/csrc` "
             "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    # PyTorch-ROCm wheels bundle their own ROCm runtime.  If this library (linked against the
+    # system runtime) is loaded first and torch afterwards, the process ends up with two
+    # runtimes and torch sees no GPU; loaded in the other order both share torch's copy.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     fp = C.POINTER(C.c_float)
     lib.nbody_default_params.argtypes = [C.POINTER(CParams)]
     lib.nbody_default_params.restype = None
     lib.nbody_create.argtypes = [C.POINTER(CParams), C.POINTER(C.c_void_p)]
+    lib.nbody_create_external.argtypes = [C.POINTER(CParams), C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_void_p)]
     lib.nbody_destroy.argtypes = [C.c_void_p]
     lib.nbody_destroy.restype = None
     lib.nbody_last_error.argtypes = [C.c_void_p]
@@ -180,12 +189,19 @@ class Params:
 class Simulation:
     """Headless drop-in for the reference's Simulation<float> (include/simulation.hpp)."""
 
-    def __init__(self, params: Params):
+    def __init__(self, params: Params, external=None):
+        """external: optional 7 device pointers (ints, 0 = skip) [pos.x, pos.y, pos.z, com.x,
+        com.y, com.z, node_size] -- the reference's Simulation(Params&, GLuint[7])."""
         self._lib = load_library()
         self.params = params
         self._h = C.c_void_p()
         cp = params.to_c()
-        rc = self._lib.nbody_create(C.byref(cp), C.byref(self._h))
+        if external is None:
+            rc = self._lib.nbody_create(C.byref(cp), C.byref(self._h))
+        else:
+            assert len(external) == 7
+            arr = (C.c_void_p * 7)(*[int(p) or None for p in external])
+            rc = self._lib.nbody_create_external(C.byref(cp), arr, C.byref(self._h))
         if rc != OK:
             self._h = C.c_void_p()
             raise RuntimeError(f"nbody_create failed with status {rc}")

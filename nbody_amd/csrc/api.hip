@@ -291,6 +291,7 @@ int post_spawn(Sim *s)
     if (rc) return rc;
     NB_HIP(s, launch_build(s));
     NB_HIP(s, launch_com(s));
+    NB_HIP(s, launch_export_view(s));
     s->spawned = true;
     s->pending_vel = false;
     s->ev_pending = 0;
@@ -444,6 +445,18 @@ void nbody_default_params(nbody_params *p)
     p->seed = 42;
 }
 
+int nbody_create_external(const nbody_params *params, void *dev_ptrs[7], nbody_t **out)
+{
+    const int rc = nbody_create(params, out);
+    if (rc != NBODY_OK || !dev_ptrs) return rc;
+    Sim *s = reinterpret_cast<Sim *>(*out);
+    for (int i = 0; i < 7; ++i) {
+        s->ext[i] = static_cast<float *>(dev_ptrs[i]);
+        s->has_ext = s->has_ext || s->ext[i] != nullptr;
+    }
+    return NBODY_OK;
+}
+
 int nbody_create(const nbody_params *params, nbody_t **out)
 {
     if (!params || !out) return NBODY_ERR_INVALID;
@@ -552,6 +565,7 @@ int nbody_update(nbody_t *h)
     NB_HIP(s, mark(EV_BUILD));
     NB_HIP(s, launch_com(s));
     NB_HIP(s, mark(EV_COM));
+    NB_HIP(s, launch_export_view(s));
     NB_HIP(s, launch_traverse(s, fuse));
     if (!fuse && !sharded) NB_HIP(s, launch_vel_kick(s));
     NB_HIP(s, mark(EV_TRAVERSE));

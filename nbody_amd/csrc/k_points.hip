@@ -273,4 +273,41 @@ hipError_t launch_vel_kick(Sim *s)
     return hipGetLastError();
 }
 
+// The reference's GL constructor makes seven viewer-owned buffers the storage of the particle
+// positions and of the octree nodes' centres of mass and sizes (src/cuda/simulation.cu:39-51,
+// 138-158).  Here the caller's device buffers receive a copy after every build instead.
+__global__ __launch_bounds__(256) void k_export_view(int n, const Counts *counts,
+                                                     const Float4 *__restrict__ posm,
+                                                     const Float4 *__restrict__ nodeA,
+                                                     const NodeB *__restrict__ nodeB, float *px,
+                                                     float *py, float *pz, float *cx, float *cy,
+                                                     float *cz, float *sz)
+{
+    const int n_oct = counts->n_oct;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < max(n, n_oct); i += gridDim.x * 256) {
+        if (i < n) {
+            const Float4 p = posm[i];
+            if (px) px[i] = p.x;
+            if (py) py[i] = p.y;
+            if (pz) pz[i] = p.z;
+        }
+        if (i < n_oct) {
+            const Float4 a = nodeA[i];
+            if (cx) cx[i] = a.x;
+            if (cy) cy[i] = a.y;
+            if (cz) cz[i] = a.z;
+            if (sz) sz[i] = nodeB[i].size;
+        }
+    }
+}
+
+hipError_t launch_export_view(Sim *s)
+{
+    if (!s->has_ext || s->n < 1) return hipSuccess;
+    hipLaunchKernelGGL(k_export_view, dim3(std::min(nblk(s->n, 256), 2048)), dim3(256), 0, s->stream,
+                       s->n, s->counts, s->posm, s->nodeA, s->nodeB, s->ext[0], s->ext[1], s->ext[2],
+                       s->ext[3], s->ext[4], s->ext[5], s->ext[6]);
+    return hipGetLastError();
+}
+
 }  // namespace nb

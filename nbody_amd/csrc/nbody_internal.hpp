@@ -121,6 +121,10 @@ struct Sim {
     float *let_boxes = nullptr;      // [64][6] device copy of the remote boxes
     uint32_t *let_counts = nullptr;  // [64] + 6 words of bounding box
 
+    // caller-owned viewer buffers [pos.x, pos.y, pos.z, com.x, com.y, com.z, node_size] (nullable)
+    float *ext[7]{};
+    bool has_ext = false;
+
     // sharded traversal
     int trav_g0 = 0, trav_g1 = -1;
     bool pending_vel = false;
@@ -162,6 +166,7 @@ hipError_t launch_vel_kick_raw(int n, float dt, float keep, const float *vhx, co
                                float *vx, float *vy, float *vz, hipStream_t st);
 hipError_t launch_count_interactions(Sim *s, unsigned long long *out);
 hipError_t launch_traverse_from(Sim *bodies, Sim *sources, bool accumulate);
+hipError_t launch_export_view(Sim *s);                      // positions + node COM/size -> ext[]
 hipError_t launch_bbox(Sim *s, uint32_t *box_dev);
 hipError_t launch_let_export(Sim *s, const float *boxes_dev, int nboxes, Float4 *out, int cap,
                              uint32_t *out_count);

@@ -305,3 +305,30 @@ def test_sharded_traversal_equals_whole():
     for b0, b1, st in parts:
         for k in ("ax", "ay", "az", "vx"):
             assert np.array_equal(st[k][b0:b1], whole[k][b0:b1]), k
+
+
+def test_external_viewer_buffers_follow_every_update():
+    """Simulation(Params&, buffers[7]) analogue: caller-owned device buffers receive positions
+    (sorted order) and the octree nodes' centres of mass and sizes after spawn and update."""
+    import torch
+    n = 5000
+    bufs = [torch.full((n if i < 3 else 2 * n,), -1.0, dtype=torch.float32, device="cuda") for i in range(7)]
+    p = nb.Params(num_points=n, theta=0.5, dt=1e-3, softening_factor=0.01, morton_bits=21)
+    with nb.Simulation(p, external=[b.data_ptr() for b in bufs]) as sim:
+        sim.spawn_disk()
+        for it in range(2):
+            st, oc = sim.get_state(), sim.get_octree()
+            torch.cuda.synchronize()
+            host = [b.cpu().numpy() for b in bufs]
+            for k, h in zip("xyz", host[:3]):
+                assert np.array_equal(h, st[k])
+            no = oc["n_oct"]
+            for k, h in zip(("comx", "comy", "comz", "size"), host[3:]):
+                assert np.array_equal(h[:no], oc[k])
+                if it == 0:
+                    assert (h[no:] == -1.0).all()      # nothing written past the node count
+            sim.update()
+    # NULL entries are skipped
+    with nb.Simulation(p, external=[bufs[0].data_ptr(), 0, 0, 0, 0, 0, 0]) as sim:
+        sim.spawn_sphere()
+        assert np.array_equal(bufs[0].cpu().numpy(), sim.get_state()["x"])
