@@ -192,6 +192,14 @@ typedef struct nbody_timings {
 } nbody_timings;
 int nbody_get_timings(nbody_t *sim, nbody_timings *out);
 
+/* Checkpoint / restart.  The reference has no state I/O (its particles only ever come from
+ * include/cuda/initial_conditions.cuh).  The file holds x,y,z,vx,vy,vz,m,ax,ay,az and the ids
+ * of all particles in the handle's current (sorted) order; a handle with the same parameters
+ * that loads it continues bit-identically to the run that saved it.  The validator's all-pairs
+ * twin is not part of the file. */
+int nbody_save_snapshot(nbody_t *sim, const char *path);
+int nbody_load_snapshot(nbody_t *sim, const char *path);
+
 /* O(N^2) direct sum (reference: compute_ap_forces, src/cuda/validator.cu:134-174) of
  * nt target bodies against ns source bodies, both float4 (x,y,z,m) device arrays.
  * acc = gravity * sum; if accumulate != 0 the result is added to ax/ay/az (tile-by-tile

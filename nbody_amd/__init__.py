@@ -81,7 +81,7 @@ EXPORTS = [
     "nbody_get_device_ptrs", "nbody_get_tree_counts", "nbody_get_octree", "nbody_get_timings",
     "nbody_direct_sum_dev", "nbody_direct_sum", "nbody_set_traversal_range", "nbody_finish_step",
     "nbody_get_validation_history", "nbody_get_bbox", "nbody_let_export", "nbody_set_sources_dev",
-    "nbody_traverse_from",
+    "nbody_traverse_from", "nbody_save_snapshot", "nbody_load_snapshot",
 ]
 
 _lib = None
@@ -137,6 +137,8 @@ def load_library() -> C.CDLL:
     dp = C.POINTER(C.c_double)
     lib.nbody_get_validation_history.argtypes = [C.c_void_p, dp, dp, dp, C.c_int32,
                                                  C.POINTER(C.c_int32)]
+    lib.nbody_save_snapshot.argtypes = [C.c_void_p, C.c_char_p]
+    lib.nbody_load_snapshot.argtypes = [C.c_void_p, C.c_char_p]
     lib.nbody_get_bbox.argtypes = [C.c_void_p, fp]
     lib.nbody_let_export.argtypes = [C.c_void_p, fp, C.c_int32, C.c_void_p, C.c_int32,
                                      C.POINTER(C.c_int32)]
@@ -335,6 +337,12 @@ class Simulation:
 
     def finish_step(self):
         self._check(self._lib.nbody_finish_step(self._h))
+
+    def save_snapshot(self, path: str):
+        self._check(self._lib.nbody_save_snapshot(self._h, os.fsencode(path)))
+
+    def load_snapshot(self, path: str):
+        self._check(self._lib.nbody_load_snapshot(self._h, os.fsencode(path)))
 
     # -- multi-GPU locally-essential-tree exchange ------------------------------
     def get_bbox(self) -> np.ndarray:

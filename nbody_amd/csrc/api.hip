@@ -865,6 +865,76 @@ int nbody_traverse_from(nbody_t *h, nbody_t *sources, int32_t accumulate)
     return NBODY_OK;
 }
 
+// ---- snapshots: binary SoA state for checkpoint / restart (the reference has no state I/O) ----
+namespace {
+struct SnapHeader {
+    char magic[8];       // "NBSNAP1"
+    int32_t n;
+    int32_t reserved;
+    float domain_size;
+    float pad;
+};
+}  // namespace
+
+int nbody_save_snapshot(nbody_t *h, const char *path)
+{
+    NB_ENTER(h);
+    if (!path) return fail(s, NBODY_ERR_INVALID, "null path");
+    if (!s->spawned) return fail(s, NBODY_ERR_STATE, "snapshot before spawn/set_state");
+    const size_t n = (size_t) s->n;
+    std::vector<float> buf(10 * n);
+    std::vector<uint32_t> id(n);
+    int rc = nbody_get_state(h, &buf[0], &buf[n], &buf[2 * n], &buf[3 * n], &buf[4 * n], &buf[5 * n],
+                             &buf[6 * n], &buf[7 * n], &buf[8 * n], &buf[9 * n], id.data());
+    if (rc) return rc;
+    SnapHeader hd{};
+    std::memcpy(hd.magic, "NBSNAP1", 8);
+    hd.n = s->n;
+    hd.domain_size = s->p.domain_size;
+    std::ofstream out(path, std::ios::binary);
+    if (!out) return fail(s, NBODY_ERR_IO, std::string("cannot open ") + path);
+    out.write(reinterpret_cast<const char *>(&hd), sizeof hd);
+    out.write(reinterpret_cast<const char *>(buf.data()), (std::streamsize) (buf.size() * 4));
+    out.write(reinterpret_cast<const char *>(id.data()), (std::streamsize) (n * 4));
+    return out ? NBODY_OK : fail(s, NBODY_ERR_IO, "write failed");
+}
+
+int nbody_load_snapshot(nbody_t *h, const char *path)
+{
+    NB_ENTER(h);
+    if (!path) return fail(s, NBODY_ERR_INVALID, "null path");
+    std::ifstream in(path, std::ios::binary);
+    if (!in) return fail(s, NBODY_ERR_IO, std::string("cannot open ") + path);
+    SnapHeader hd{};
+    in.read(reinterpret_cast<char *>(&hd), sizeof hd);
+    if (!in || std::memcmp(hd.magic, "NBSNAP1", 8) != 0) return fail(s, NBODY_ERR_IO, "not a snapshot file");
+    if (hd.n != s->cap) return fail(s, NBODY_ERR_INVALID, "snapshot particle count differs from num_points");
+    const size_t n = (size_t) hd.n;
+    std::vector<float> buf(10 * n);
+    std::vector<uint32_t> id(n);
+    in.read(reinterpret_cast<char *>(buf.data()), (std::streamsize) (buf.size() * 4));
+    in.read(reinterpret_cast<char *>(id.data()), (std::streamsize) (n * 4));
+    if (!in) return fail(s, NBODY_ERR_IO, "truncated snapshot");
+    int rc = upload_state(s, &buf[0], &buf[n], &buf[2 * n], &buf[3 * n], &buf[4 * n], &buf[5 * n], &buf[6 * n]);
+    if (rc) return rc;
+    // upload_state sorted the particles (identity if the snapshot was taken after a step) and
+    // reset accelerations and ids; carry both through the same permutation.
+    std::vector<uint32_t> perm(n);
+    NB_HIP(s, hipMemcpy(perm.data(), s->id[s->cur], n * 4, hipMemcpyDeviceToHost));
+    std::vector<float> a(3 * n);
+    std::vector<uint32_t> nid(n);
+    for (size_t i = 0; i < n; ++i) {
+        const size_t src = perm[i];
+        a[i] = buf[7 * n + src]; a[n + i] = buf[8 * n + src]; a[2 * n + i] = buf[9 * n + src];
+        nid[i] = id[src];
+    }
+    NB_HIP(s, hipMemcpy(s->ax, &a[0], n * 4, hipMemcpyHostToDevice));
+    NB_HIP(s, hipMemcpy(s->ay, &a[n], n * 4, hipMemcpyHostToDevice));
+    NB_HIP(s, hipMemcpy(s->az, &a[2 * n], n * 4, hipMemcpyHostToDevice));
+    NB_HIP(s, hipMemcpy(s->id[s->cur], nid.data(), n * 4, hipMemcpyHostToDevice));
+    return NBODY_OK;
+}
+
 int nbody_write_validation_history(nbody_t *h, const char *csv_path)
 {
     NB_ENTER(h);

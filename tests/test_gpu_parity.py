@@ -332,3 +332,25 @@ def test_external_viewer_buffers_follow_every_update():
     with nb.Simulation(p, external=[bufs[0].data_ptr(), 0, 0, 0, 0, 0, 0]) as sim:
         sim.spawn_sphere()
         assert np.array_equal(bufs[0].cpu().numpy(), sim.get_state()["x"])
+
+
+def test_snapshot_restart_is_bit_identical(tmp_path):
+    n = 20000
+    p = nb.Params(num_points=n, theta=0.6, dt=1e-3, softening_factor=0.01, morton_bits=21)
+    path = str(tmp_path / "state.nbsnap")
+    with nb.Simulation(p) as a:
+        a.spawn_disk()
+        a.step(3)
+        a.save_snapshot(path)
+        a.step(4)
+        ref = a.get_state()
+    with nb.Simulation(p) as b:
+        b.load_snapshot(path)
+        b.step(4)
+        got = b.get_state()
+    for k in ("x", "y", "z", "vx", "vy", "vz", "ax", "ay", "az", "id"):
+        assert np.array_equal(ref[k], got[k]), k
+    with nb.Simulation(nb.Params(num_points=n + 1)) as c, pytest.raises(RuntimeError):
+        c.load_snapshot(path)
+    with nb.Simulation(p) as d, pytest.raises(RuntimeError):
+        d.load_snapshot(str(tmp_path / "missing"))
