@@ -39,6 +39,10 @@ enum {
 enum {
     NBODY_FLAG_TIMING = 1u << 0,       /* record per-stage HIP events every step             */
     NBODY_FLAG_NO_FUSED_VEL = 1u << 1, /* run the velocity half-kick as its own kernel        */
+    NBODY_FLAG_DEBUG_SMALL_STACK = 1u << 9, /* test aid: the traversal runs with a node stack of
+                                            32 usable entries, so that its overflow handling
+                                            (push-backs, depth-first rounds) is exercised;
+                                            results are unchanged                            */
     NBODY_FLAG_DEBUG_WALK_ONLY = 1u << 8 /* profiling aid: traversal walks the tree and fills
                                             its source lists but skips the force arithmetic
                                             (accelerations are meaningless)                  */

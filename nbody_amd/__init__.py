@@ -22,6 +22,7 @@ ERR_CAPACITY = 6
 FLAG_TIMING = 1 << 0
 FLAG_NO_FUSED_VEL = 1 << 1
 FLAG_DEBUG_WALK_ONLY = 1 << 8
+FLAG_DEBUG_SMALL_STACK = 1 << 9
 
 IC_UNIFORM, IC_SPHERE, IC_DISK, IC_PLUMMER = 0, 1, 2, 3
 

@@ -74,7 +74,8 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
     int n, int g0, int g1, const Float4 *__restrict__ body_posm, const Float4 *__restrict__ posm,
     const v8f *__restrict__ posm2, const Float4 *__restrict__ nodeA,
     const NodeB *__restrict__ nodeB, float theta, float eps2, float gravity, float domain,
-    float dt, float keep, const TravTail *__restrict__ tail, int cur, int accumulate)
+    float dt, float keep, const TravTail *__restrict__ tail, int cur, int accumulate,
+    int stack_limit)
 {
     __shared__ WaveLds lds[TRAV_WAVES];
 
@@ -285,23 +286,36 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
         return dmin;
     };
 
+    uint32_t rounds = 0;
     while (true) {
         while (leaf_n >= 64 || (sp == 0 && pend_n == 0 && leaf_n > 0)) process_leaves();
         if (sp == 0 && pend_n == 0) break;
+        if (++rounds > (1u << 22)) {   // every round retires a node for good; a tree has < 2^22
+            if (lane == 0) atomicOr(tail->err, (uint32_t) DEV_ERR_STACK);   // of them per group walk
+            break;
+        }
 
         PROF_T0();
-        const int room = TRAV_STACK - TRAV_RESERVE - sp;
-        const int leaf_room = (TRAV_LEAF_STACK - leaf_n) >> 3;   // a node adds up to 8 leaves
-        bool valid, approx;
+        // Node-stack discipline.  A round normally pops everything it can test (up to 64) and
+        // pushes the inner children of the nodes it opens for as long as they fit under
+        // stack_limit - TRAV_RESERVE; opened nodes whose children do not fit go back on the
+        // stack unexpanded (they occupy slots the round has just freed).  With fewer than 7
+        // free slots below that mark the round pops ONE node and always expands it: such
+        // rounds are depth-first, add at most 7 entries net per tree level (8 children for the
+        // node popped), and the reserve of 7 x 24 entries covers every level a 63-bit key has.
+        const int room = stack_limit - TRAV_RESERVE - sp;
+        const int leaf_room = TRAV_LEAF_STACK - leaf_n;
+        bool valid, approx, may_defer;
+        int node;
         Float4 A;
         NodeB B;
         // undecided candidates first once 32 have gathered (or nothing else is left), as long
         // as their children are sure to fit
-        const int kx = (pend_n >= 32 || sp == 0) ? min(min(pend_n, 32), min(room / 7, leaf_room)) : 0;
+        const int kx = (pend_n >= 32 || sp == 0) ? min(min(pend_n, 32), min(max(room, 0) >> 3, leaf_room >> 3)) : 0;
         if (kx > 0) {
             const int slot = lane & 31;
             const bool have = slot < kx;
-            const int node = have ? L.pend[pend_n - kx + slot] : 0;
+            node = have ? L.pend[pend_n - kx + slot] : 0;
             pend_n -= kx;
             A = nodeA[node];
             B = nodeB[node];
@@ -309,11 +323,12 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
             dmin = fminf(dmin, __shfl_xor(dmin, 32, 64));
             valid = have && lane < 32;
             approx = valid && (__fdiv_rn(B.size * B.size, dmin) < th2);
+            may_defer = false;
         } else {
-            // leaf_n < 64 here
-            const int k = min(min(min(sp, 64), max(room / 7, 1)), leaf_room);
+            may_defer = room >= 7;
+            const int k = may_defer ? min(sp, 64) : 1;
             valid = lane < k;
-            const int node = valid ? L.stack[sp - k + lane] : 0;
+            node = valid ? L.stack[sp - k + lane] : 0;
             sp -= k;
             A = nodeA[node];
             B = nodeB[node];
@@ -361,19 +376,29 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
         const uint32_t cl = (uint32_t) __popc(lmask);
         const uint32_t packed = (nc - cl) | (cl << 16);
         const uint32_t inc = wave_incl_scan_u32(packed);
-        const uint32_t tot = (uint32_t) __shfl(inc, 63, 64);
         const uint32_t exc = inc - packed;
+        // the lanes whose children fit are a prefix of the opened lanes (inc is monotone)
+        // (a node has up to 8 inner children and the round has freed at least its own slot)
+        const bool fits = open && (!may_defer || ((int) (inc & 0xffffu) <= room + 1 &&
+                                                  (int) (inc >> 16) <= leaf_room));
+        const unsigned long long fm = __ballot(fits);
+        const unsigned long long bm = __ballot(open && !fits);
+        const int n_back = (int) __popcll(bm);
+        if (open && !fits) L.stack[sp + mbcnt(bm)] = node;
+        const uint32_t tot = fm ? (uint32_t) __builtin_amdgcn_readlane((int) inc, 63 - (int) __builtin_clzll(fm)) : 0u;
         const int tot_i = (int) (tot & 0xffffu), tot_l = (int) (tot >> 16);
-        if (sp + tot_i > TRAV_STACK || leaf_n + tot_l > TRAV_LEAF_STACK) {
+        if (sp + n_back + tot_i > TRAV_STACK || leaf_n + tot_l > TRAV_LEAF_STACK) {
             if (lane == 0) atomicOr(tail->err, (uint32_t) DEV_ERR_STACK);  // unreachable by construction
             break;
         }
-        int di = sp + (int) (exc & 0xffffu), dl = leaf_n + (int) (exc >> 16);
-        for (uint32_t c = 0; c < nc; ++c) {
-            const int child = B.first + (int) c;
-            if ((lmask >> c) & 1u) L.leaf[dl++] = child; else L.stack[di++] = child;
+        if (fits) {
+            int di = sp + n_back + (int) (exc & 0xffffu), dl = leaf_n + (int) (exc >> 16);
+            for (uint32_t c = 0; c < nc; ++c) {
+                const int child = B.first + (int) c;
+                if ((lmask >> c) & 1u) L.leaf[dl++] = child; else L.stack[di++] = child;
+            }
         }
-        sp += tot_i;
+        sp += n_back + tot_i;
         leaf_n += tot_l;
         __builtin_amdgcn_wave_barrier();
         PROF_ADD(0);
@@ -530,8 +555,11 @@ static hipError_t traverse_impl(Sim *s, Sim *src, bool fuse_vel, int acc_flag)
     hipLaunchKernelGGL((k_traverse<GG, FV, WO>), dim3(grid), dim3(64 * TRAV_WAVES), 0, s->stream,    \
                        s->n, g0, g1, s->posm, src->posm, (const v8f *) src->posm2, src->nodeA,       \
                        src->nodeB, s->p.theta, eps2, s->p.gravity, s->p.domain_size, s->p.dt, keep,  \
-                       s->trav_tail, c, acc_flag)
+                       s->trav_tail, c, acc_flag, stack_limit)
         const bool walk_only = (s->p.flags & NBODY_FLAG_DEBUG_WALK_ONLY) != 0;
+        // test aid: a node stack with 32 usable entries makes unexpanded push-backs and
+        // depth-first single-node rounds the common case
+        const int stack_limit = (s->p.flags & NBODY_FLAG_DEBUG_SMALL_STACK) ? TRAV_RESERVE + 32 : TRAV_STACK;
         if (walk_only) {
             if (s->group == 64) NB_TRAV(64, false, true); else NB_TRAV(32, false, true);
         } else if (s->group == 64) {

@@ -354,3 +354,25 @@ def test_snapshot_restart_is_bit_identical(tmp_path):
         c.load_snapshot(path)
     with nb.Simulation(p) as d, pytest.raises(RuntimeError):
         d.load_snapshot(str(tmp_path / "missing"))
+
+
+@pytest.mark.parametrize("kind,n,bits,theta", [(nb.IC_DISK, 30000, 21, 0.5), (nb.IC_SPHERE, 50000, 10, 0.3),
+                                               (nb.IC_PLUMMER, 40000, 21, 0.0)])
+def test_tiny_node_stack_gives_the_same_lists(kind, n, bits, theta):
+    """With 32 usable node-stack entries almost every round pushes opened nodes back or runs
+    depth-first; the interaction lists must not change (theta = 0 opens the whole tree)."""
+    ic = nb.sample_ic(kind, n, 17, p0=0.1, p1=1.0)
+    res = []
+    for flags in (0, nb.FLAG_DEBUG_SMALL_STACK):
+        p = nb.Params(num_points=n, theta=theta, dt=1e-4, softening_factor=0.01, morton_bits=bits,
+                      flags=flags)
+        with nb.Simulation(p) as sim:
+            sim.set_state(ic["x"], ic["y"], ic["z"], ic["m"], ic["vx"], ic["vy"], ic["vz"])
+            sim.update()
+            res.append((sim.get_octree()["list_len"], sim.get_state()))
+    assert np.array_equal(res[0][0], res[1][0])
+    if theta == 0.0:
+        assert (res[0][0][:-1] == n).all()
+    for k in ("ax", "ay", "az"):
+        scale = np.sqrt(res[0][1]["ax"] ** 2 + res[0][1]["ay"] ** 2 + res[0][1]["az"] ** 2)
+        assert np.max(np.abs(res[0][1][k] - res[1][1][k]) / scale) < 1e-4   # summation order only
