@@ -376,3 +376,30 @@ def test_tiny_node_stack_gives_the_same_lists(kind, n, bits, theta):
     for k in ("ax", "ay", "az"):
         scale = np.sqrt(res[0][1]["ax"] ** 2 + res[0][1]["ay"] ** 2 + res[0][1]["az"] ** 2)
         assert np.max(np.abs(res[0][1][k] - res[1][1][k]) / scale) < 1e-4   # summation order only
+
+
+def test_headline_workload_first_step_matches_oracle():
+    """The benchmark's own workload at full size (2,097,152-particle sphere, theta = 0.6,
+    eps = 0.1, 63-bit keys): tree sizes, every group's interaction-list length and the exact
+    interaction total equal the host oracle's; accelerations within the float tolerance."""
+    n, theta, eps, dt = 2_097_152, 0.6, 0.1, 1e-6
+    ic = nb.sample_ic(nb.IC_SPHERE, n, 42)
+    with new_sim(n, morton_bits=21, theta=theta, dt=dt, softening_factor=eps,
+                 flags=nb.FLAG_TIMING) as sim:
+        sim.set_state(ic["x"], ic["y"], ic["z"], ic["m"])
+        sim.update()
+        gpu = sim.get_octree()
+        st = sim.get_state()
+        tim = sim.get_timings()
+    ref0 = O.full_build(ic["x"], ic["y"], ic["z"], ic["m"], 5.0, 21, 32)   # the spawn build
+    # v = a = 0: the first update does not move anything and re-sorts sorted particles
+    ref = O.full_build(ref0["xs"], ref0["ys"], ref0["zs"], ref0["ms"], 5.0, 21, 32)
+    assert_build_equal(gpu, ref)
+    assert np.array_equal(st["x"], ref["xs"]) and np.array_equal(st["id"], ref0["perm"].astype(np.uint32))
+    ax, ay, az, ll = O.traverse(ref["tree"], ref["com"], ref["xs"], ref["ys"], ref["zs"], ref["ms"],
+                                64, theta, eps, 1.0, 5.0)
+    assert np.array_equal(gpu["list_len"], ll)
+    assert tim["interactions"] == int(ll.astype(np.int64).sum()) * 64
+    err = np.sqrt((st["ax"] - ax) ** 2 + (st["ay"] - ay) ** 2 + (st["az"] - az) ** 2)
+    ref_n = np.sqrt(ax.astype(np.float64) ** 2 + ay ** 2 + az ** 2)
+    assert (err / ref_n).max() < 1e-4 and (err / ref_n).mean() < 1e-5
