@@ -246,6 +246,17 @@ int nbody_finish_step(nbody_t *sim);
  * nbody_traverse_from: accelerations of `sim`'s particles due to the tree of `sources` (same
  *   device and key width; theta/softening/gravity of `sim`); added to ax/ay/az when
  *   accumulate != 0. */
+/* nbody_set_particles: replace the handle's particles by `count` particles, 1 <= count <=
+ *   num_points, given as host arrays: positions, velocities (NULL = 0), masses, the
+ *   accelerations of their last force evaluation (NULL = 0) and caller-defined 32-bit ids
+ *   (NULL = 0..count-1).  Sorts and builds like nbody_set_state but keeps accelerations and
+ *   ids, so the step sequence continues as if the particles had always lived here: this is
+ *   how particles migrate between the domains when the decomposition is re-balanced.  The
+ *   handle keeps that count until the next set_particles/set_state/spawn. */
+int nbody_set_particles(nbody_t *sim, int32_t count, const float *x, const float *y,
+                        const float *z, const float *vx, const float *vy, const float *vz,
+                        const float *m, const float *ax, const float *ay, const float *az,
+                        const uint32_t *id);
 int nbody_get_bbox(nbody_t *sim, float *lo_hi);
 int nbody_let_export(nbody_t *sim, const float *boxes, int32_t nboxes, float *out_dev,
                      int32_t capacity, int32_t *counts);

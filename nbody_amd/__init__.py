@@ -82,7 +82,7 @@ EXPORTS = [
     "nbody_get_device_ptrs", "nbody_get_tree_counts", "nbody_get_octree", "nbody_get_timings",
     "nbody_direct_sum_dev", "nbody_direct_sum", "nbody_set_traversal_range", "nbody_finish_step",
     "nbody_get_validation_history", "nbody_get_bbox", "nbody_let_export", "nbody_set_sources_dev",
-    "nbody_traverse_from", "nbody_save_snapshot", "nbody_load_snapshot",
+    "nbody_traverse_from", "nbody_save_snapshot", "nbody_load_snapshot", "nbody_set_particles",
 ]
 
 _lib = None
@@ -140,6 +140,7 @@ def load_library() -> C.CDLL:
                                                  C.POINTER(C.c_int32)]
     lib.nbody_save_snapshot.argtypes = [C.c_void_p, C.c_char_p]
     lib.nbody_load_snapshot.argtypes = [C.c_void_p, C.c_char_p]
+    lib.nbody_set_particles.argtypes = [C.c_void_p, C.c_int32] + [fp] * 10 + [C.POINTER(C.c_uint32)]
     lib.nbody_get_bbox.argtypes = [C.c_void_p, fp]
     lib.nbody_let_export.argtypes = [C.c_void_p, fp, C.c_int32, C.c_void_p, C.c_int32,
                                      C.POINTER(C.c_int32)]
@@ -287,8 +288,23 @@ class Simulation:
                 arrs.append(a)
         self._check(self._lib.nbody_set_state(self._h, *[_fptr(a) for a in arrs]))
 
+    def count(self) -> int:
+        """Particles currently held (num_points unless set_particles/set_sources changed it)."""
+        return int(self.device_view().n)
+
+    def set_particles(self, x, y, z, m, vx=None, vy=None, vz=None, ax=None, ay=None, az=None, id=None):
+        """Variable-count set_state that keeps accelerations and ids (domain re-balancing)."""
+        n = len(x)
+        arrs = [None if a is None else np.ascontiguousarray(a, np.float32)
+                for a in (x, y, z, vx, vy, vz, m, ax, ay, az)]
+        assert all(a is None or a.shape == (n,) for a in arrs)
+        ids = None if id is None else np.ascontiguousarray(id, np.uint32)
+        self._check(self._lib.nbody_set_particles(
+            self._h, n, *[_fptr(a) for a in arrs],
+            None if ids is None else ids.ctypes.data_as(C.POINTER(C.c_uint32))))
+
     def get_state(self) -> dict:
-        n = self.params.num_points
+        n = self.count()
         names = ("x", "y", "z", "vx", "vy", "vz", "m", "ax", "ay", "az")
         out = {k: np.empty(n, np.float32) for k in names}
         out["id"] = np.empty(n, np.uint32)
@@ -304,7 +320,7 @@ class Simulation:
 
     def get_octree(self) -> dict:
         """All build products of the last update/spawn as numpy arrays."""
-        n = self.params.num_points
+        n = self.count()
         U, M, no = self.tree_counts()
         ngroups = (n + self.params.traversal_group_size - 1) // self.params.traversal_group_size
         sizes = {"codes_sorted": n, "perm": n, "unique": U, "first_pt": U + 1,
@@ -328,7 +344,7 @@ class Simulation:
         return v
 
     def direct_sum(self):
-        n = self.params.num_points
+        n = self.count()
         out = [np.empty(n, np.float32) for _ in range(3)]
         self._check(self._lib.nbody_direct_sum(self._h, *[_fptr(a) for a in out]))
         return out

@@ -301,9 +301,9 @@ int post_spawn(Sim *s)
 }
 
 int upload_state(Sim *s, const float *x, const float *y, const float *z, const float *vx,
-                 const float *vy, const float *vz, const float *m)
+                 const float *vy, const float *vz, const float *m, int count = -1)
 {
-    s->n = s->cap;
+    s->n = count < 0 ? s->cap : count;
     const size_t n = (size_t) s->n, b = n * 4;
     const int c = s->cur;
     std::vector<uint32_t> ids(n);
@@ -412,6 +412,33 @@ int validator_step(Sim *s)
     s->hist_err[s->val_step] = err / n;
     s->val_step = (s->val_step + 1) % s->p.num_steps_validator;  // wraps like the reference
     if (s->val_count < (int) cap) s->val_count++;
+    return NBODY_OK;
+}
+
+// upload_state + accelerations and ids carried through the sort it performs (identity when
+// the particles arrive in the sorted order of a previous step).
+int set_particles(Sim *s, int count, const float *x, const float *y, const float *z, const float *vx,
+                  const float *vy, const float *vz, const float *m, const float *ax, const float *ay,
+                  const float *az, const uint32_t *id)
+{
+    int rc = upload_state(s, x, y, z, vx, vy, vz, m, count);
+    if (rc) return rc;
+    if (!ax && !ay && !az && !id) return NBODY_OK;
+    const size_t n = (size_t) count;
+    std::vector<uint32_t> perm(n), nid(n);
+    NB_HIP(s, hipMemcpy(perm.data(), s->id[s->cur], n * 4, hipMemcpyDeviceToHost));
+    std::vector<float> a(n);
+    const float *src[3] = {ax, ay, az};
+    float *dst[3] = {s->ax, s->ay, s->az};
+    for (int k = 0; k < 3; ++k) {
+        if (!src[k]) continue;
+        for (size_t i = 0; i < n; ++i) a[i] = src[k][perm[i]];
+        NB_HIP(s, hipMemcpy(dst[k], a.data(), n * 4, hipMemcpyHostToDevice));
+    }
+    if (id) {
+        for (size_t i = 0; i < n; ++i) nid[i] = id[perm[i]];
+        NB_HIP(s, hipMemcpy(s->id[s->cur], nid.data(), n * 4, hipMemcpyHostToDevice));
+    }
     return NBODY_OK;
 }
 
@@ -915,24 +942,20 @@ int nbody_load_snapshot(nbody_t *h, const char *path)
     in.read(reinterpret_cast<char *>(buf.data()), (std::streamsize) (buf.size() * 4));
     in.read(reinterpret_cast<char *>(id.data()), (std::streamsize) (n * 4));
     if (!in) return fail(s, NBODY_ERR_IO, "truncated snapshot");
-    int rc = upload_state(s, &buf[0], &buf[n], &buf[2 * n], &buf[3 * n], &buf[4 * n], &buf[5 * n], &buf[6 * n]);
-    if (rc) return rc;
-    // upload_state sorted the particles (identity if the snapshot was taken after a step) and
-    // reset accelerations and ids; carry both through the same permutation.
-    std::vector<uint32_t> perm(n);
-    NB_HIP(s, hipMemcpy(perm.data(), s->id[s->cur], n * 4, hipMemcpyDeviceToHost));
-    std::vector<float> a(3 * n);
-    std::vector<uint32_t> nid(n);
-    for (size_t i = 0; i < n; ++i) {
-        const size_t src = perm[i];
-        a[i] = buf[7 * n + src]; a[n + i] = buf[8 * n + src]; a[2 * n + i] = buf[9 * n + src];
-        nid[i] = id[src];
-    }
-    NB_HIP(s, hipMemcpy(s->ax, &a[0], n * 4, hipMemcpyHostToDevice));
-    NB_HIP(s, hipMemcpy(s->ay, &a[n], n * 4, hipMemcpyHostToDevice));
-    NB_HIP(s, hipMemcpy(s->az, &a[2 * n], n * 4, hipMemcpyHostToDevice));
-    NB_HIP(s, hipMemcpy(s->id[s->cur], nid.data(), n * 4, hipMemcpyHostToDevice));
-    return NBODY_OK;
+    return set_particles(s, hd.n, &buf[0], &buf[n], &buf[2 * n], &buf[3 * n], &buf[4 * n], &buf[5 * n],
+                         &buf[6 * n], &buf[7 * n], &buf[8 * n], &buf[9 * n], id.data());
+}
+
+int nbody_set_particles(nbody_t *h, int32_t count, const float *x, const float *y, const float *z,
+                        const float *vx, const float *vy, const float *vz, const float *m,
+                        const float *ax, const float *ay, const float *az, const uint32_t *id)
+{
+    NB_ENTER(h);
+    if (count < 1 || count > s->cap) return fail(s, NBODY_ERR_INVALID, "set_particles: count outside [1, num_points]");
+    if (!x || !y || !z || !m) return fail(s, NBODY_ERR_INVALID, "set_particles: x, y, z, m required");
+    if (s->p.num_steps_validator > 0 && count != s->cap)
+        return fail(s, NBODY_ERR_STATE, "set_particles: a handle with a validator keeps num_points particles");
+    return set_particles(s, count, x, y, z, vx, vy, vz, m, ax, ay, az, id);
 }
 
 int nbody_write_validation_history(nbody_t *h, const char *csv_path)

@@ -140,6 +140,85 @@ class LetStepper:
         b.add_remote(recv)
         b.finish_step()
 
+    def rebalance(self, sample=4096, seed=0):
+        """Re-draws the domains and migrates particles (call between steps, every few hundred:
+        it goes through host memory).  Every rank contributes `sample` of its positions; all
+        ranks bisect the gathered sample identically (orb_cuts), classify their particles and
+        exchange them with one all-to-all.  Requires backend.get_particles() -> dict of host
+        arrays (x,y,z,vx,vy,vz,m,ax,ay,az float32; id uint32) and backend.set_particles(dict).
+        Returns the number of particles this rank gave away."""
+        import numpy as np
+        b, W, me = self.b, self.world, self.rank
+        st = b.get_particles()
+        n = len(st["x"])
+        pos = np.stack([st["x"], st["y"], st["z"]], 1)
+        rng = np.random.default_rng(seed * 1000003 + me)
+        pick = rng.choice(n, size=sample, replace=n < sample)
+        mine = torch.from_numpy(np.ascontiguousarray(pos[pick], np.float32).reshape(-1))
+        allp = torch.empty(W * sample * 3, dtype=torch.float32)
+        if b.device.type == "cuda":     # RCCL moves device memory only
+            g = allp.to(b.device)
+            dist.all_gather_into_tensor(g, mine.to(b.device), group=self.pg)
+            allp = g.cpu()
+        else:
+            dist.all_gather_into_tensor(allp, mine, group=self.pg)
+        cuts = orb_cuts(allp.numpy().reshape(-1, 3), W)
+        dest = orb_assign(cuts, pos)
+        order = np.argsort(dest, kind="stable")
+        send_rows = np.bincount(dest, minlength=W).tolist()
+        names = ("x", "y", "z", "vx", "vy", "vz", "m", "ax", "ay", "az")
+        rec = np.empty((n, 11), np.float32)
+        for k, name in enumerate(names):
+            rec[:, k] = st[name][order]
+        rec[:, 10] = st["id"][order].view(np.float32)          # ids ride along bit for bit
+        sc = torch.tensor(send_rows, dtype=torch.int64, device=b.device)
+        rc = torch.empty_like(sc)
+        dist.all_to_all_single(rc, sc, group=self.pg)
+        recv_rows = [int(v) for v in rc.cpu()]
+        send = torch.from_numpy(rec).to(b.device)
+        recv = torch.empty(sum(recv_rows), 11, dtype=torch.float32, device=b.device)
+        dist.all_to_all_single(recv, send, recv_rows, send_rows, group=self.pg)
+        got = recv.cpu().numpy()
+        new = {name: np.ascontiguousarray(got[:, k]) for k, name in enumerate(names)}
+        new["id"] = np.ascontiguousarray(got[:, 10]).view(np.uint32)
+        b.set_particles(new)
+        return n - send_rows[me]
+
+
+def orb_cuts(points, parts):
+    """Orthogonal recursive bisection of `points` (k, 3) into `parts` boxes covering all of
+    space: nested tuples (axis, threshold, parts_left, left, right), leaves = None.  Every cut
+    goes across the longest axis of the piece at the quantile that matches the ranks on
+    either side -- the same rule as domain_slices."""
+    import numpy as np
+    pts = np.asarray(points, np.float64)
+    if parts == 1:
+        return None
+    left = parts // 2
+    axis = int(np.argmax(pts.max(0) - pts.min(0))) if len(pts) else 0
+    if len(pts) >= 2:
+        v = np.sort(pts[:, axis])
+        k = min(max(len(v) * left // parts, 1), len(v) - 1)
+        thr = 0.5 * (v[k - 1] + v[k])
+    else:
+        thr = float(pts[0, axis]) if len(pts) else 0.0
+    m = pts[:, axis] < thr
+    return (axis, float(thr), left, orb_cuts(pts[m], left), orb_cuts(pts[~m], parts - left))
+
+
+def orb_assign(cuts, pos, first=0):
+    """Domain index of every row of pos (k, 3) under orb_cuts' tree."""
+    import numpy as np
+    pos = np.asarray(pos)
+    out = np.full(len(pos), first, np.int64)
+    if cuts is None or len(pos) == 0:
+        return out
+    axis, thr, left, lo, hi = cuts
+    m = pos[:, axis].astype(np.float64) < thr
+    out[m] = orb_assign(lo, pos[m], first)
+    out[~m] = orb_assign(hi, pos[~m], first + left)
+    return out
+
 
 def domain_slices(x, y, z, world):
     """Index arrays of `world` domains of (nearly) equal particle count with disjoint, tight
@@ -233,6 +312,18 @@ class GpuBackend:
     def finish_step(self):
         self.sim.finish_step()
 
+    def get_particles(self):
+        return self.sim.get_state()
+
+    def set_particles(self, st):
+        if len(st["x"]) > self.sim.params.num_points:
+            raise RuntimeError(f"domain received {len(st['x'])} particles, handle capacity is "
+                               f"{self.sim.params.num_points}: create it with head-room")
+        self.sim.set_particles(st["x"], st["y"], st["z"], st["m"], st["vx"], st["vy"], st["vz"],
+                               st["ax"], st["ay"], st["az"], st["id"])
+        self.n = len(st["x"])
+        self.sim.set_traversal_range(0, 0)
+
 
 class GpuLetBackend:
     """LetStepper backend over two nbody_amd.Simulation handles on one GPU: `sim` holds the
@@ -302,3 +393,15 @@ class GpuLetBackend:
 
     def finish_step(self):
         self.sim.finish_step()
+
+    def get_particles(self):
+        return self.sim.get_state()
+
+    def set_particles(self, st):
+        if len(st["x"]) > self.sim.params.num_points:
+            raise RuntimeError(f"domain received {len(st['x'])} particles, handle capacity is "
+                               f"{self.sim.params.num_points}: create it with head-room")
+        self.sim.set_particles(st["x"], st["y"], st["z"], st["m"], st["vx"], st["vy"], st["vz"],
+                               st["ax"], st["ay"], st["az"], st["id"])
+        self.n = len(st["x"])
+        self.sim.set_traversal_range(0, 0)

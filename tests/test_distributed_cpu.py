@@ -205,8 +205,18 @@ class OracleLetBackend:
         self.v = [(np.float32(0.5) * a * np.float32(self.dt) + h).astype(np.float32)
                   for a, h in zip(self.acc, self.vh)]
 
+    def get_particles(self):
+        return dict(x=self.x, y=self.y, z=self.z, m=self.m, vx=self.v[0], vy=self.v[1], vz=self.v[2],
+                    ax=self.acc[0], ay=self.acc[1], az=self.acc[2], id=self.gid.astype(np.uint32))
 
-def _let_worker(rank, world, port, n, q):
+    def set_particles(self, st):
+        self.x, self.y, self.z, self.m = st["x"], st["y"], st["z"], st["m"]
+        self.v = [st["vx"], st["vy"], st["vz"]]
+        self.acc = [st["ax"], st["ay"], st["az"]]
+        self.gid = st["id"].astype(np.int64)
+
+
+def _let_worker(rank, world, port, n, q, rebalance_at=-1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ic = _ic(n)
@@ -214,16 +224,19 @@ def _let_worker(rank, world, port, n, q):
     be = OracleLetBackend(ic, idx, 64, 0.5, 1e-3, 0.01, 21)
     st = parallel.LetStepper(be)
     sent = []
-    for _ in range(3):
+    moved = 0
+    for i in range(3):
+        if i == rebalance_at:
+            moved = st.rebalance(sample=512, seed=i)
         st.step()
         sent.append((st.last_sent, st.last_received))
-    q.put((rank, be.gid, be.x, be.y, be.v[0], be.acc[0], be.acc[1], be.acc[2], sent))
+    q.put((rank, be.gid, be.x, be.y, be.v[0], be.acc[0], be.acc[1], be.acc[2], sent, moved))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n", [(2, 3000), (3, 2500)])
-def test_let_stepper_tracks_single_rank_and_direct_sum(world, n):
+@pytest.mark.parametrize("world,n,rebalance_at", [(2, 3000, -1), (3, 2500, -1), (3, 2500, 2)])
+def test_let_stepper_tracks_single_rank_and_direct_sum(world, n, rebalance_at):
     """Domain decomposition over gloo ranks: every rank owns n/world particles and imports a
     locally-essential tree from the others.  The forces are not bit-identical to a single
     tree (different trees), so the check is accuracy against a float64 direct sum at the
@@ -231,7 +244,8 @@ def test_let_stepper_tracks_single_rank_and_direct_sum(world, n):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_let_worker, args=(r, world, port, n, q)) for r in range(world)]
+    procs = [ctx.Process(target=_let_worker, args=(r, world, port, n, q, rebalance_at))
+             for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in range(world)]
@@ -240,11 +254,16 @@ def test_let_stepper_tracks_single_rank_and_direct_sum(world, n):
         assert p.exitcode == 0
     ic = _ic(n)
     x, y, vx, ax, ay, az = (np.full(n, np.nan, np.float32) for _ in range(6))
-    for rank, gid, rx, ry, rvx, rax, ray, raz, sent in res:
+    for rank, gid, rx, ry, rvx, rax, ray, raz, sent, moved in res:
         x[gid], y[gid], vx[gid], ax[gid], ay[gid], az[gid] = rx, ry, rvx, rax, ray, raz
         # a surface term: every step something is exchanged, far fewer records than particles
         assert all(0 < s < n and 0 < r < n for s, r in sent)
     assert not np.isnan(x).any()                      # every particle owned exactly once
+    assert sum(len(r[1]) for r in res) == n
+    if rebalance_at >= 0:
+        # the disk has moved for two steps: the fresh bisection differs from the initial one
+        assert sum(r[9] for r in res) > 0
+        assert max(len(r[1]) for r in res) - min(len(r[1]) for r in res) < 0.2 * n / world
     ref = OracleBackend(ic, n, 64, 0.5, 1e-3, 0.01, 21)
     for _ in range(3):
         ref.update()

@@ -179,3 +179,28 @@ def test_source_handle_shrinks_and_grows():
                 assert mx < 1e-5
     with pytest.raises(RuntimeError):
         h.set_sources_dev(dev.data_ptr(), cap + 1)
+
+
+def test_set_particles_with_head_room_equals_exact_size_handle():
+    """A handle created for more particles than it holds steps exactly like one of the exact
+    size; accelerations and ids given to set_particles survive its sort."""
+    n, cap = 7001, 9000
+    ic = nb.sample_ic(nb.IC_DISK, n, 4)
+    with nb.Simulation(_params(n, 21, 0.5)) as a, nb.Simulation(_params(cap, 21, 0.5)) as b:
+        a.set_state(ic["x"], ic["y"], ic["z"], ic["m"], ic["vx"], ic["vy"], ic["vz"])
+        a.step(2)
+        sa = a.get_state()
+        # hand a's state (sorted order, with accelerations) to b in a scrambled order
+        perm = np.random.default_rng(0).permutation(n)
+        b.set_particles(*[sa[k][perm] for k in ("x", "y", "z", "m", "vx", "vy", "vz", "ax", "ay", "az")],
+                        id=sa["id"][perm])
+        assert b.count() == n
+        sb = b.get_state()
+        for k in ("x", "vx", "ax", "az", "id"):
+            assert np.array_equal(sa[k], sb[k]), k          # the sort undid the scramble
+        a.step(2)
+        b.step(2)
+        sa, sb = a.get_state(), b.get_state()
+        for k in ("x", "y", "z", "vx", "vy", "vz", "ax", "ay", "az", "id"):
+            assert np.array_equal(sa[k], sb[k]), k
+        assert a.tree_counts() == b.tree_counts()

@@ -106,14 +106,16 @@ rank, world, n = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(sys
 dist.init_process_group("gloo", rank=rank, world_size=world)
 ic = nb.sample_ic(nb.IC_SPHERE, n, 5)
 idx = parallel.domain_slices(ic["x"], ic["y"], ic["z"], world)[rank]
-sim = nb.Simulation(nb.Params(num_points=len(idx), morton_bits=21, theta=0.6, dt=1e-3,
+cap = int(len(idx) * 1.3) + 64                      # head-room for the re-balance
+sim = nb.Simulation(nb.Params(num_points=cap, morton_bits=21, theta=0.6, dt=1e-3,
                               softening_factor=0.01, device_id=0))
-sim.set_state(*[ic[k][idx] for k in ("x", "y", "z", "m", "vx", "vy", "vz")])
+sim.set_particles(ic["x"][idx], ic["y"][idx], ic["z"][idx], ic["m"][idx], id=idx.astype(np.uint32))
 st = parallel.LetStepper(parallel.GpuLetBackend(sim, "cuda:0", exchange_device="cpu"))
-for _ in range(2):
-    st.step()
+st.step()
+moved = st.rebalance(sample=1024, seed=1)
+st.step()
 s = sim.get_state()
-np.savez(sys.argv[3] + f"/rank{rank}.npz", gid=idx[s["id"]], sent=st.last_sent,
+np.savez(sys.argv[3] + f"/rank{rank}.npz", gid=s["id"], sent=st.last_sent, moved=moved,
          **{k: s[k] for k in ("x", "y", "z", "m", "ax", "ay", "az")})
 dist.barrier()
 dist.destroy_process_group()
@@ -137,12 +139,14 @@ def test_let_stepper_two_processes_share_the_gpu(tmp_path):
     for p in procs:
         out, _ = p.communicate(timeout=110)
         assert p.returncode == 0, out
-    full = {k: np.empty(n, np.float32) for k in ("x", "y", "z", "m", "ax", "ay", "az")}
+    full = {k: np.full(n, np.nan, np.float32) for k in ("x", "y", "z", "m", "ax", "ay", "az")}
     for r in range(world):
         d = np.load(tmp_path / f"rank{r}.npz")
-        assert 0 < int(d["sent"]) <= n // world
+        assert 0 < int(d["sent"]) <= len(d["gid"])
+        assert abs(len(d["gid"]) - n // world) < 0.1 * n
         for k in full:
             full[k][d["gid"]] = d[k]
+    assert not np.isnan(full["x"]).any()            # every particle is owned by exactly one rank
     ref = O.direct_f64(full["x"], full["y"], full["z"], full["m"], 0.01, 1.0)
     mean, mx = O.acc_error(full["ax"], full["ay"], full["az"], *ref)
     assert mean < 1e-2 and mx < 0.3, (mean, mx)
