@@ -37,7 +37,11 @@ enum {
 
 /* nbody_params.flags */
 enum {
-    NBODY_FLAG_TIMING = 1u << 0,       /* record per-stage HIP events every step             */
+    NBODY_FLAG_TIMING = 1u << 0,       /* HIP events at a step's begin and around its traversal:
+                                          nbody_timings.ms_traverse, ms_total, interactions;
+                                          ms_build then holds everything before the traversal */
+    NBODY_FLAG_TIMING_STAGES = 1u << 2, /* with TIMING: also mark integrate / sort / build / COM
+                                          (three more events, a few microseconds each)        */
     NBODY_FLAG_NO_FUSED_VEL = 1u << 1, /* run the velocity half-kick as its own kernel        */
     NBODY_FLAG_DEBUG_SMALL_STACK = 1u << 9, /* test aid: the traversal runs with a node stack of
                                             32 usable entries, so that its overflow handling

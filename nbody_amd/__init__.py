@@ -21,6 +21,7 @@ OK = 0
 ERR_CAPACITY = 6
 FLAG_TIMING = 1 << 0
 FLAG_NO_FUSED_VEL = 1 << 1
+FLAG_TIMING_STAGES = 1 << 2
 FLAG_DEBUG_WALK_ONLY = 1 << 8
 FLAG_DEBUG_SMALL_STACK = 1 << 9
 

@@ -577,8 +577,12 @@ int nbody_update(nbody_t *h)
     const int slot = s->ev_head;
     if (timing && s->ev_pending == TIMING_RING)
         return fail(s, NBODY_ERR_STATE, "timing ring full: call nbody_get_timings");
+    // every recorded event costs a few microseconds of stream time: without
+    // NBODY_FLAG_TIMING_STAGES only the step's begin and the traversal's two ends are marked
+    const bool stages = (s->p.flags & NBODY_FLAG_TIMING_STAGES) != 0;
     auto mark = [&](int k) -> hipError_t {
-        return timing ? hipEventRecord(s->ev[slot][k], s->stream) : hipSuccess;
+        const bool wanted = timing && (stages || k == EV_BEGIN || k == EV_COM || k == EV_TRAVERSE);
+        return wanted ? hipEventRecord(s->ev[slot][k], s->stream) : hipSuccess;
     };
     const bool sharded = s->trav_g1 >= 0;
     const bool fuse = !sharded && !(s->p.flags & NBODY_FLAG_NO_FUSED_VEL);
@@ -759,8 +763,13 @@ int nbody_get_timings(nbody_t *h, nbody_timings *out)
     for (int i = 0; i < pending; ++i) {
         const int slot = ((s->ev_head - pending + i) % TIMING_RING + TIMING_RING) % TIMING_RING;
         float t[EV_COUNT] = {0};
-        for (int k = 1; k < EV_COUNT; ++k)
-            NB_HIP(s, hipEventElapsedTime(&t[k], s->ev[slot][k - 1], s->ev[slot][k]));
+        if (s->p.flags & NBODY_FLAG_TIMING_STAGES) {
+            for (int k = 1; k < EV_COUNT; ++k)
+                NB_HIP(s, hipEventElapsedTime(&t[k], s->ev[slot][k - 1], s->ev[slot][k]));
+        } else {   // coarse: everything before the traversal is reported as "build"
+            NB_HIP(s, hipEventElapsedTime(&t[EV_BUILD], s->ev[slot][EV_BEGIN], s->ev[slot][EV_COM]));
+            NB_HIP(s, hipEventElapsedTime(&t[EV_TRAVERSE], s->ev[slot][EV_COM], s->ev[slot][EV_TRAVERSE]));
+        }
         float tot = 0;
         NB_HIP(s, hipEventElapsedTime(&tot, s->ev[slot][EV_BEGIN], s->ev[slot][EV_TRAVERSE]));
         out->ms_integrate += t[EV_INTEGRATE];

@@ -257,15 +257,20 @@ def test_sort_properties_at_full_size():
         assert np.isclose(g["mass"][0], n, rtol=1e-5)
 
 
-def test_timings_and_interaction_count():
+@pytest.mark.parametrize("stages", [False, True])
+def test_timings_and_interaction_count(stages):
     n = 16384
     ic = make_ic("plummer", n)
-    with new_sim(n, morton_bits=21, theta=0.6, flags=nb.FLAG_TIMING) as sim:
+    flags = nb.FLAG_TIMING | (nb.FLAG_TIMING_STAGES if stages else 0)
+    with new_sim(n, morton_bits=21, theta=0.6, flags=flags) as sim:
         sim.set_state(ic["x"], ic["y"], ic["z"], ic["m"])
         sim.step(3)
         t = sim.get_timings()
         ll = sim.get_octree()["list_len"]
     assert t["steps"] == 3 and t["ms_traverse"] > 0 and t["ms_total"] >= t["ms_traverse"]
+    assert t["ms_build"] > 0
+    # the per-stage split exists only with FLAG_TIMING_STAGES
+    assert (t["ms_sort"] > 0 and t["ms_com"] > 0 and t["ms_integrate"] > 0) == stages
     assert t["interactions"] >= 3 * 64 * int(ll.min()) * (n // 64)
     assert abs(t["interactions"] / 3 - 64 * int(ll.astype(np.int64).sum())) < 0.05 * t["interactions"] / 3
 
