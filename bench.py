@@ -41,6 +41,7 @@ FLOP_PER_INTERACTION = 20          # GPU-Gems/Nyland convention for one softened
 BUILD_BYTES_PER_PARTICLE = 300     # algorithmic bytes of integrate+sort+permute+build+COM
 PEAK_FP32_TFLOPS = 157.3           # MI355X FP32 vector peak
 PEAK_HBM_GBS = 8000.0              # MI355X HBM3E peak
+SUSTAINED_CLOCK_GHZ = 2.0          # shader clock measured inside k_traverse (profiles/r1_walk_profile.txt)
 REFERENCE_MS_PER_STEP = 150.0      # reference README, RTX 500 Ada, 2,097,152 particles, theta=0.6
 
 
@@ -379,9 +380,13 @@ def main():
                                          "peak_interactions_per_s": round(1024 * 2.4e9 * 2),
                                          "achieved_interactions_per_s": round(inter_step_rank0 / (trav_ms * 1e-3)) if trav_ms else None,
                                          "frac": round(inter_step_rank0 / (trav_ms * 1e-3) / (1024 * 2.4e9 * 2), 4) if trav_ms else None,
+                                         "sustained_clock_ghz": SUSTAINED_CLOCK_GHZ,
+                                         "frac_at_sustained_clock": round(inter_step_rank0 / (trav_ms * 1e-3) / (1024 * SUSTAINED_CLOCK_GHZ * 1e9 * 2), 4) if trav_ms else None,
                                          "note": "12 packed ops (4 cycles) + 2 v_rsq_f32 (8 cycles) per wave "
                                                  "per two sources: the instruction-issue floor of the force "
-                                                 "arithmetic at 2.4 GHz on 1024 SIMDs"}},
+                                                 "arithmetic on 1024 SIMDs, at the nominal 2.4 GHz and at the "
+                                                 "clock measured inside this kernel (s_memtime against "
+                                                 "s_memrealtime, profiles/r1_walk_profile.txt)"}},
             "roofline_build": {"bound": "hbm", "achieved": round(build_gbs, 1), "peak": PEAK_HBM_GBS,
                                "unit": "GB/s", "frac": round(build_gbs / PEAK_HBM_GBS, 4),
                                "note": "300 algorithmic B/particle over integrate+sort+build+COM"},

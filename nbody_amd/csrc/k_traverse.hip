@@ -101,6 +101,7 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
 #if NB_WALK_PROFILE
     long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const long long t_begin = clock64();
+    const long long r_begin = wall_clock64();
 #endif
     int sp = 0, leaf_n = 0;
     {
@@ -424,7 +425,8 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
 #if NB_WALK_PROFILE
     if (lane == 0) {
         prof_acc[3] = clock64() - t_begin;
-        for (int i = 0; i < 5; ++i) atomicAdd(&g_walk_prof[i], (unsigned long long) prof_acc[i]);
+        prof_acc[5] = wall_clock64() - r_begin;
+        for (int i = 0; i < 6; ++i) atomicAdd(&g_walk_prof[i], (unsigned long long) prof_acc[i]);
     }
 #endif
     if (lane == 0) tail->list_len[g] = total;
@@ -575,9 +577,11 @@ static hipError_t traverse_impl(Sim *s, Sim *src, bool fuse_vel, int acc_flag)
         (void) hipMemcpyToSymbol(HIP_SYMBOL(g_walk_prof), z, sizeof z);
         const double tot = (double) h[3];
         fprintf(stderr, "walk profile: groups %d  MAC rounds/group %.1f  wave-cycles/group %.0f | "
-                        "MAC+push %.1f%%  leaf runs (scalar path) %.1f%%  ring flush %.1f%%  other %.1f%%\n",
+                        "MAC+push %.1f%%  leaf runs (scalar path) %.1f%%  ring flush %.1f%%  other %.1f%%  "
+                        "| shader clock %.0f MHz (s_memtime ticks per 100 MHz tick)\n",
                 g1 - g0, (double) h[4] / (g1 - g0), tot / (g1 - g0), 100.0 * h[0] / tot,
-                100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * (tot - h[0] - h[1] - h[2]) / tot);
+                100.0 * h[1] / tot, 100.0 * h[2] / tot, 100.0 * (tot - h[0] - h[1] - h[2]) / tot,
+                100.0 * tot / (double) h[5]);
 #endif
     }
     return hipGetLastError();
