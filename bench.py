@@ -262,6 +262,7 @@ def main():
         total_inter = int(tim["interactions"])
     st = sim.get_state()
     ok = bool(np.isfinite(st["ax"]).all() and np.isfinite(st["x"]).all())
+    e_start = sum(sim.tree_energy()) if world == 1 and not args.walk_only else None
     evolved = None
     if world == 1 and args.evolve_steps > 0 and not args.walk_only:
         left = args.evolve_steps
@@ -285,6 +286,10 @@ def main():
                    "half_mass_radius": round(float(np.median(r)), 4),
                    "r99": round(float(np.quantile(r, 0.99)), 4),
                    "finite": bool(np.isfinite(s3["ax"]).all() and np.isfinite(s3["x"]).all())}
+        e_end = sum(sim.tree_energy())
+        evolved["energy"] = {"after_timed_region": e_start, "after_collapse": e_end,
+                             "relative_change": round((e_end - e_start) / abs(e_start), 6),
+                             "note": "kinetic + tree potential (nbody_tree_energy)"}
     sim.close()
 
     stage = None

@@ -200,6 +200,14 @@ typedef struct nbody_timings {
 } nbody_timings;
 int nbody_get_timings(nbody_t *sim, nbody_timings *out);
 
+/* Energy of the current state with the potential evaluated through the tree, O(N log N), so
+ * that energy conservation can be followed at sizes where the validator's all-pairs energy
+ * (reference: src/cuda/validator.cu:19-63) is out of reach:
+ *   kinetic = sum m v^2/2,  potential = -G/2 sum_i m_i sum_{j!=i} m_j / sqrt(d_ij^2 + eps^2),
+ * the inner sum over the sources the force traversal uses for i's group (monopoles for
+ * accepted nodes).  Does not change the state.  Outputs may be NULL. */
+int nbody_tree_energy(nbody_t *sim, double *kinetic, double *potential);
+
 /* Checkpoint / restart.  The reference has no state I/O (its particles only ever come from
  * include/cuda/initial_conditions.cuh).  The file holds x,y,z,vx,vy,vz,m,ax,ay,az and the ids
  * of all particles in the handle's current (sorted) order; a handle with the same parameters

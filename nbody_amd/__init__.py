@@ -84,6 +84,7 @@ EXPORTS = [
     "nbody_direct_sum_dev", "nbody_direct_sum", "nbody_set_traversal_range", "nbody_finish_step",
     "nbody_get_validation_history", "nbody_get_bbox", "nbody_let_export", "nbody_set_sources_dev",
     "nbody_traverse_from", "nbody_save_snapshot", "nbody_load_snapshot", "nbody_set_particles",
+    "nbody_tree_energy",
 ]
 
 _lib = None
@@ -139,6 +140,7 @@ def load_library() -> C.CDLL:
     dp = C.POINTER(C.c_double)
     lib.nbody_get_validation_history.argtypes = [C.c_void_p, dp, dp, dp, C.c_int32,
                                                  C.POINTER(C.c_int32)]
+    lib.nbody_tree_energy.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.nbody_save_snapshot.argtypes = [C.c_void_p, C.c_char_p]
     lib.nbody_load_snapshot.argtypes = [C.c_void_p, C.c_char_p]
     lib.nbody_set_particles.argtypes = [C.c_void_p, C.c_int32] + [fp] * 10 + [C.POINTER(C.c_uint32)]
@@ -355,6 +357,12 @@ class Simulation:
 
     def finish_step(self):
         self._check(self._lib.nbody_finish_step(self._h))
+
+    def tree_energy(self):
+        """(kinetic, potential) of the current state, potential through the tree."""
+        ke, pe = C.c_double(), C.c_double()
+        self._check(self._lib.nbody_tree_energy(self._h, C.byref(ke), C.byref(pe)))
+        return ke.value, pe.value
 
     def save_snapshot(self, path: str):
         self._check(self._lib.nbody_save_snapshot(self._h, os.fsencode(path)))

@@ -7,6 +7,7 @@
 // the constants of Simulation<T>::spawn_* (src/cuda/simulation.cu:170-220).
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -52,7 +53,7 @@ void free_all(Sim *s)
     F(s->rt_level); F(s->rt_lb); F(s->rt_le); F(s->rt_left); F(s->rt_right); F(s->depth_key);
     F(s->bfs); F(s->octid); F(s->o_depth); F(s->o_first_child); F(s->o_num_children); F(s->o_lb);
     F(s->o_le); F(s->o_level); F(s->o_pb); F(s->o_pe); F(s->o_parent); F(s->o_size); F(s->o_wsum);
-    F(s->nodeA); F(s->nodeB); F(s->list_len); F(s->inter_dev); F(s->trav_tail);
+    F(s->nodeA); F(s->nodeB); F(s->list_len); F(s->inter_dev); F(s->trav_tail); F(s->pot);
     F(s->tw_posm); F(s->tw_pot); F(s->ds_pot); F(s->let_boxes); F(s->let_counts);
     for (int k = 0; k < 3; ++k) { F(s->tw_v[k]); F(s->tw_vh[k]); F(s->tw_a[k]); F(s->ds_a[k]); }
     if (s->counts_host) (void) hipHostFree(s->counts_host);
@@ -898,6 +899,41 @@ int nbody_traverse_from(nbody_t *h, nbody_t *sources, int32_t accumulate)
     hipError_t e = launch_traverse_from(s, src, accumulate != 0);
     s->trav_g0 = g0; s->trav_g1 = g1;
     NB_HIP(s, e);
+    return NBODY_OK;
+}
+
+// Energy of the current state with the potential taken from the tree (the reference only has
+// the all-pairs energy of its validator, src/cuda/validator.cu:19-63):
+//   kinetic = sum m v^2 / 2,  potential = -G/2 sum_i m_i sum_{j != i} m_j / sqrt(d_ij^2 + eps^2)
+// where the inner sum runs over the same sources the force traversal uses for i's group.
+int nbody_tree_energy(nbody_t *h, double *kinetic, double *potential)
+{
+    NB_ENTER(h);
+    if (!s->spawned) return fail(s, NBODY_ERR_STATE, "energy before spawn/set_state");
+    if (s->pending_vel) return fail(s, NBODY_ERR_STATE, "nbody_finish_step not called");
+    const size_t n = (size_t) s->n, b = n * 4;
+    if (!s->pot) {
+        NB_HIP(s, dalloc(&s->pot, (size_t) s->cap));
+        NB_HIP(s, hipMemcpy(reinterpret_cast<char *>(s->trav_tail) + offsetof(TravTail, pot), &s->pot,
+                            sizeof(float *), hipMemcpyHostToDevice));
+    }
+    NB_HIP(s, launch_potential(s));
+    const int c = s->cur;
+    std::vector<float> m(n), vx(n), vy(n), vz(n), pot(n);
+    NB_HIP(s, hipMemcpyAsync(m.data(), s->m[c], b, hipMemcpyDeviceToHost, s->stream));
+    NB_HIP(s, hipMemcpyAsync(vx.data(), s->vx[c], b, hipMemcpyDeviceToHost, s->stream));
+    NB_HIP(s, hipMemcpyAsync(vy.data(), s->vy[c], b, hipMemcpyDeviceToHost, s->stream));
+    NB_HIP(s, hipMemcpyAsync(vz.data(), s->vz[c], b, hipMemcpyDeviceToHost, s->stream));
+    NB_HIP(s, hipMemcpyAsync(pot.data(), s->pot, b, hipMemcpyDeviceToHost, s->stream));
+    int rc = fetch_counts(s);
+    if (rc) return rc;
+    double ke = 0, pe = 0;
+    for (size_t i = 0; i < n; ++i) {
+        ke += 0.5 * m[i] * ((double) vx[i] * vx[i] + (double) vy[i] * vy[i] + (double) vz[i] * vz[i]);
+        pe -= 0.5 * (double) s->p.gravity * m[i] * pot[i];
+    }
+    if (kinetic) *kinetic = ke;
+    if (potential) *potential = pe;
     return NBODY_OK;
 }
 

@@ -69,7 +69,12 @@ struct alignas(16) WaveLds {
     int pend[TRAV_PEND];   // candidates waiting for the exact distance test
 };
 
-template <int G, bool FUSE_VEL, bool WALK_ONLY>
+// MODE: 0 = forces (the step), 1 = walk only (profiling aid: no force arithmetic), 2 = potential
+// (sum of m / sqrt(d^2 + eps^2) over the same sources instead of the force; writes tail->pot
+// and nothing else; `accumulate` bit 1 removes the body's own term m_i / eps).
+constexpr int TRAV_FORCE = 0, TRAV_WALK_ONLY = 1, TRAV_POTENTIAL = 2;
+
+template <int G, bool FUSE_VEL, int MODE>
 __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
     int n, int g0, int g1, const Float4 *__restrict__ body_posm, const Float4 *__restrict__ posm,
     const v8f *__restrict__ posm2, const Float4 *__restrict__ nodeA,
@@ -120,13 +125,18 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
     const float dinit = domain * domain * 3.0f;
 
     auto pair_force = [&](const v4f a, const v4f c) {
-        if (WALK_ONLY) {  // profiling aid: keep the LDS reads alive, skip the arithmetic
+        if (MODE == TRAV_WALK_ONLY) {  // keep the LDS reads alive, skip the arithmetic
             fx2 += a.xy; fy2 += c.xy;
             return;
         }
         const v2f dx = a.xy - px2, dy = a.zw - py2, dz = c.xy - pz2;
         const v2f s = __builtin_elementwise_fma(
             dz, dz, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dx, dx, e2)));
+        if (MODE == TRAV_POTENTIAL) {   // fx2 doubles as the potential accumulator
+            const v2f inv1 = {__builtin_amdgcn_rsqf(s.x), __builtin_amdgcn_rsqf(s.y)};
+            fx2 = __builtin_elementwise_fma(inv1, c.zw, fx2);
+            return;
+        }
         const v2f s3 = s * s * s;
         v2f inv = {__builtin_amdgcn_rsqf(s3.x), __builtin_amdgcn_rsqf(s3.y)};
         inv *= c.zw;
@@ -155,10 +165,15 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
 
     // Sources of one pair record held in SGPRs (wave-uniform): no LDS, no VGPR staging.
     auto pair_force_s = [&](const v8f r) {
-        if (WALK_ONLY) { fx2 += v2f{r[0], r[1]}; return; }
+        if (MODE == TRAV_WALK_ONLY) { fx2 += v2f{r[0], r[1]}; return; }
         const v2f dx = v2f{r[0], r[1]} - px2, dy = v2f{r[2], r[3]} - py2, dz = v2f{r[4], r[5]} - pz2;
         const v2f s = __builtin_elementwise_fma(
             dz, dz, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dx, dx, e2)));
+        if (MODE == TRAV_POTENTIAL) {
+            const v2f inv1 = {__builtin_amdgcn_rsqf(s.x), __builtin_amdgcn_rsqf(s.y)};
+            fx2 = __builtin_elementwise_fma(inv1, v2f{r[6], r[7]}, fx2);
+            return;
+        }
         const v2f s3 = s * s * s;
         v2f inv = {__builtin_amdgcn_rsqf(s3.x), __builtin_amdgcn_rsqf(s3.y)};
         inv *= v2f{r[6], r[7]};
@@ -429,6 +444,14 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
         for (int i = 0; i < 6; ++i) atomicAdd(&g_walk_prof[i], (unsigned long long) prof_acc[i]);
     }
 #endif
+    if (MODE == TRAV_POTENTIAL) {
+        if (active) {
+            float p = fx;
+            if (accumulate & 2) p -= me.w * __builtin_amdgcn_rsqf(eps2);   // the body itself
+            tail->pot[b] = (accumulate & 1) ? tail->pot[b] + p : p;
+        }
+        return;
+    }
     if (lane == 0) tail->list_len[g] = total;
     if (active) {
         float axv = gravity * fx, ayv = gravity * fy, azv = gravity * fz;
@@ -543,7 +566,7 @@ __global__ __launch_bounds__(256) void k_direct(const Float4 *__restrict__ targe
 }
 
 // Bodies of `s` against the tree of `src` (the same handle for an ordinary step).
-static hipError_t traverse_impl(Sim *s, Sim *src, bool fuse_vel, int acc_flag)
+static hipError_t traverse_impl(Sim *s, Sim *src, bool fuse_vel, int acc_flag, bool potential = false)
 {
     const int ngroups = (s->n + s->group - 1) / s->group;
     const int g0 = s->trav_g1 < 0 ? 0 : s->trav_g0;
@@ -554,7 +577,7 @@ static hipError_t traverse_impl(Sim *s, Sim *src, bool fuse_vel, int acc_flag)
         const float eps2 = s->p.softening_factor * s->p.softening_factor;
         const float keep = 1.0f - s->p.velocity_dampening;
 #define NB_TRAV(GG, FV, WO)                                                                      \
-    hipLaunchKernelGGL((k_traverse<GG, FV, WO>), dim3(grid), dim3(64 * TRAV_WAVES), 0, s->stream,    \
+    hipLaunchKernelGGL((k_traverse<GG, FV, (WO)>), dim3(grid), dim3(64 * TRAV_WAVES), 0, s->stream,    \
                        s->n, g0, g1, s->posm, src->posm, (const v8f *) src->posm2, src->nodeA,       \
                        src->nodeB, s->p.theta, eps2, s->p.gravity, s->p.domain_size, s->p.dt, keep,  \
                        s->trav_tail, c, acc_flag, stack_limit)
@@ -562,12 +585,14 @@ static hipError_t traverse_impl(Sim *s, Sim *src, bool fuse_vel, int acc_flag)
         // test aid: a node stack with 32 usable entries makes unexpanded push-backs and
         // depth-first single-node rounds the common case
         const int stack_limit = (s->p.flags & NBODY_FLAG_DEBUG_SMALL_STACK) ? TRAV_RESERVE + 32 : TRAV_STACK;
-        if (walk_only) {
-            if (s->group == 64) NB_TRAV(64, false, true); else NB_TRAV(32, false, true);
+        if (potential) {
+            if (s->group == 64) NB_TRAV(64, false, TRAV_POTENTIAL); else NB_TRAV(32, false, TRAV_POTENTIAL);
+        } else if (walk_only) {
+            if (s->group == 64) NB_TRAV(64, false, TRAV_WALK_ONLY); else NB_TRAV(32, false, TRAV_WALK_ONLY);
         } else if (s->group == 64) {
-            if (fuse_vel) NB_TRAV(64, true, false); else NB_TRAV(64, false, false);
+            if (fuse_vel) NB_TRAV(64, true, TRAV_FORCE); else NB_TRAV(64, false, TRAV_FORCE);
         } else {
-            if (fuse_vel) NB_TRAV(32, true, false); else NB_TRAV(32, false, false);
+            if (fuse_vel) NB_TRAV(32, true, TRAV_FORCE); else NB_TRAV(32, false, TRAV_FORCE);
         }
 #undef NB_TRAV
 #if NB_WALK_PROFILE
@@ -588,6 +613,17 @@ static hipError_t traverse_impl(Sim *s, Sim *src, bool fuse_vel, int acc_flag)
 }
 
 hipError_t launch_traverse(Sim *s, bool fuse_vel) { return traverse_impl(s, s, fuse_vel, 0); }
+
+// tail->pot[b] = sum over the sources of the body's group of m / sqrt(d^2 + eps^2), own term
+// removed; every group, whatever traversal range is set.
+hipError_t launch_potential(Sim *s)
+{
+    const int g0 = s->trav_g0, g1 = s->trav_g1;
+    s->trav_g1 = -1;
+    const hipError_t e = traverse_impl(s, s, false, 2, true);
+    s->trav_g0 = g0; s->trav_g1 = g1;
+    return e;
+}
 
 hipError_t launch_traverse_from(Sim *bodies, Sim *sources, bool accumulate)
 {

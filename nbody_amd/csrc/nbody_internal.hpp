@@ -40,6 +40,7 @@ struct TravTail {
     uint32_t *err;
     float *vhx[2], *vhy[2], *vhz[2];
     float *vx[2], *vy[2], *vz[2];
+    float *pot;
 };
 
 // Device-resident counters written by the build kernels (one int each).
@@ -117,6 +118,7 @@ struct Sim {
     NodeB *nodeB = nullptr;
     uint32_t *list_len = nullptr; // [ceil(n/group)]
     TravTail *trav_tail = nullptr;
+    float *pot = nullptr;            // per-body potential sums (allocated by the first energy call)
     // LET exchange scratch
     float *let_boxes = nullptr;      // [64][6] device copy of the remote boxes
     uint32_t *let_counts = nullptr;  // [64] + 6 words of bounding box
@@ -166,6 +168,7 @@ hipError_t launch_vel_kick_raw(int n, float dt, float keep, const float *vhx, co
                                float *vx, float *vy, float *vz, hipStream_t st);
 hipError_t launch_count_interactions(Sim *s, unsigned long long *out);
 hipError_t launch_traverse_from(Sim *bodies, Sim *sources, bool accumulate);
+hipError_t launch_potential(Sim *s);                        // -> s->pot
 hipError_t launch_export_view(Sim *s);                      // positions + node COM/size -> ext[]
 hipError_t launch_bbox(Sim *s, uint32_t *box_dev);
 hipError_t launch_let_export(Sim *s, const float *boxes_dev, int nboxes, Float4 *out, int cap,

@@ -79,3 +79,26 @@ def test_energy_drift_1000_steps_32k_disk():
     assert np.abs((e - e[0]) / e[0]).max() < 1e-2       # drift of the tree run
     assert np.abs((ea - ea[0]) / ea[0]).max() < 1e-2    # drift of the all-pairs run
     assert err.mean() < 8e-4 and err.max() < 2e-3       # published theta = 0.5 band
+
+
+@pytest.mark.parametrize("theta,rtol", [(0.0, 5e-5), (0.5, 2e-3)])   # float32 per-body sums
+def test_tree_energy_matches_all_pairs_energy(theta, rtol):
+    """nbody_tree_energy: kinetic exact, potential through the tree; theta = 0 makes the tree
+    sum an all-pairs sum."""
+    n = 8192
+    ic = nb.sample_ic(nb.IC_DISK, n, 2)
+    p = nb.Params(num_points=n, theta=theta, dt=1e-3, softening_factor=0.01, morton_bits=21)
+    with nb.Simulation(p) as sim:
+        sim.set_state(ic["x"], ic["y"], ic["z"], ic["m"], ic["vx"], ic["vy"], ic["vz"])
+        sim.step(2)
+        st = sim.get_state()
+        ke, pe = sim.tree_energy()
+        again = sim.get_state()
+    for k in ("x", "vx", "ax"):
+        assert np.array_equal(st[k], again[k])             # the state is untouched
+    ke_ref = float(np.sum(0.5 * st["m"].astype(np.float64) * (st["vx"].astype(np.float64) ** 2 +
+                                                              st["vy"].astype(np.float64) ** 2 +
+                                                              st["vz"].astype(np.float64) ** 2)))
+    e_ref = O.energy_f64(st["x"], st["y"], st["z"], st["vx"], st["vy"], st["vz"], st["m"], 0.01, 1.0)
+    assert abs(ke - ke_ref) <= 1e-12 * abs(ke_ref)
+    assert abs((ke + pe) - e_ref) <= rtol * abs(e_ref), (ke + pe, e_ref)
