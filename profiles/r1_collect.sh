@@ -8,8 +8,8 @@ ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_r1
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace21 -o bench -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-alt-bits > $OUT/bench_bits21_under_rocprof.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace10 -o bench -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-alt-bits --morton-bits 10 > $OUT/bench_bits10_under_rocprof.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace21 -o bench -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-alt-bits --evolve-steps 0 > $OUT/bench_bits21_under_rocprof.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace10 -o bench -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-alt-bits --evolve-steps 0 --morton-bits 10 > $OUT/bench_bits10_under_rocprof.log 2>&1
 timeout -s KILL 120 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -- python3 $ROOT/scratch/prof_step.py 21 2097152 3 > $OUT/pmc_fetch.log 2>&1
 timeout -s KILL 120 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -- python3 $ROOT/scratch/prof_step.py 21 2097152 3 > $OUT/pmc_write.log 2>&1
 timeout -s KILL 120 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VALU_TRANS_F32 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU -d $OUT/pmc_sq1 -- python3 $ROOT/scratch/prof_step.py 21 2097152 3 > $OUT/pmc_sq1.log 2>&1
