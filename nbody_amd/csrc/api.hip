@@ -603,6 +603,7 @@ int nbody_update(nbody_t *h)
     NB_HIP(s, mark(EV_TRAVERSE));
     if (timing) {
         NB_HIP(s, launch_count_interactions(s, (unsigned long long *) (s->inter_dev + slot)));
+        s->tf_calls[slot] = 0;
         s->ev_head = (slot + 1) % TIMING_RING;
         s->ev_pending++;
     }
@@ -765,7 +766,7 @@ int nbody_get_timings(nbody_t *h, nbody_timings *out)
         const int slot = ((s->ev_head - pending + i) % TIMING_RING + TIMING_RING) % TIMING_RING;
         float t[EV_COUNT] = {0};
         if (s->p.flags & NBODY_FLAG_TIMING_STAGES) {
-            for (int k = 1; k < EV_COUNT; ++k)
+            for (int k = 1; k <= EV_TRAVERSE; ++k)
                 NB_HIP(s, hipEventElapsedTime(&t[k], s->ev[slot][k - 1], s->ev[slot][k]));
         } else {   // coarse: everything before the traversal is reported as "build"
             NB_HIP(s, hipEventElapsedTime(&t[EV_BUILD], s->ev[slot][EV_BEGIN], s->ev[slot][EV_COM]));
@@ -773,6 +774,12 @@ int nbody_get_timings(nbody_t *h, nbody_timings *out)
         }
         float tot = 0;
         NB_HIP(s, hipEventElapsedTime(&tot, s->ev[slot][EV_BEGIN], s->ev[slot][EV_TRAVERSE]));
+        for (int k = 0; k < s->tf_calls[slot]; ++k) {   // traversals driven through nbody_traverse_from
+            float tf = 0;
+            NB_HIP(s, hipEventElapsedTime(&tf, s->ev[slot][EV_TF0_BEGIN + 2 * k], s->ev[slot][EV_TF0_END + 2 * k]));
+            t[EV_TRAVERSE] += tf;
+            tot += tf;
+        }
         out->ms_integrate += t[EV_INTEGRATE];
         out->ms_sort += t[EV_SORT];
         out->ms_build += t[EV_BUILD];
@@ -894,11 +901,22 @@ int nbody_traverse_from(nbody_t *h, nbody_t *sources, int32_t accumulate)
     }
     if (!src->spawned) return fail(s, NBODY_ERR_STATE, "traverse_from: sources hold no tree");
     if (src != s) NB_HIP(s, hipStreamSynchronize(src->stream));
+    // with NBODY_FLAG_TIMING up to two calls per step (own tree, imported tree) are timed and
+    // their interactions counted into the record of the last nbody_update()
+    const bool timed = (s->p.flags & NBODY_FLAG_TIMING) && s->ev_pending > 0;
+    const int slot = (s->ev_head + TIMING_RING - 1) % TIMING_RING;
+    const int k = timed ? s->tf_calls[slot] : 2;
+    if (k < 2) NB_HIP(s, hipEventRecord(s->ev[slot][EV_TF0_BEGIN + 2 * k], s->stream));
     const int g0 = s->trav_g0, g1 = s->trav_g1;
     s->trav_g1 = -1;  // all groups
     hipError_t e = launch_traverse_from(s, src, accumulate != 0);
     s->trav_g0 = g0; s->trav_g1 = g1;
     NB_HIP(s, e);
+    if (k < 2) {
+        NB_HIP(s, hipEventRecord(s->ev[slot][EV_TF0_END + 2 * k], s->stream));
+        NB_HIP(s, launch_count_interactions(s, (unsigned long long *) (s->inter_dev + slot), true));
+        s->tf_calls[slot] = k + 1;
+    }
     return NBODY_OK;
 }
 

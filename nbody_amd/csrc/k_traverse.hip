@@ -630,13 +630,16 @@ hipError_t launch_traverse_from(Sim *bodies, Sim *sources, bool accumulate)
     return traverse_impl(bodies, sources, false, accumulate ? 1 : 0);
 }
 
-hipError_t launch_count_interactions(Sim *s, unsigned long long *out)
+// all_groups_add: count every group and add to *out (after a nbody_traverse_from call);
+// otherwise *out = count over the traversal range of the step.
+hipError_t launch_count_interactions(Sim *s, unsigned long long *out, bool all_groups_add)
 {
     const int ngroups = (s->n + s->group - 1) / s->group;
-    const int g0 = s->trav_g1 < 0 ? 0 : s->trav_g0;
-    const int g1 = s->trav_g1 < 0 ? ngroups : std::min(s->trav_g1, ngroups);
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(unsigned long long), s->stream);
+    const int g0 = (all_groups_add || s->trav_g1 < 0) ? 0 : s->trav_g0;
+    const int g1 = (all_groups_add || s->trav_g1 < 0) ? ngroups : std::min(s->trav_g1, ngroups);
+    hipError_t e = all_groups_add ? hipSuccess : hipMemsetAsync(out, 0, sizeof(unsigned long long), s->stream);
     if (e != hipSuccess) return e;
+    if (g1 <= g0) return hipSuccess;
     const int grid = std::max(1, std::min(64, (g1 - g0 + 255) / 256));
     hipLaunchKernelGGL(k_count_interactions, dim3(grid), dim3(256), 0, s->stream, s->n, s->group,
                        g0, g1, s->list_len, out);

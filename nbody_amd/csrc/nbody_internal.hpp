@@ -23,7 +23,9 @@ constexpr int TRAV_LEAF_STACK = 544;                // LDS leaf stack entries pe
 constexpr int TRAV_PEND = 96;                       // LDS queue of candidates awaiting the exact test
 constexpr int MAX_DEPTH_BINS = 256;                 // depth key space of the node ranking pass
 constexpr int TIMING_RING = 64;
-enum { EV_BEGIN = 0, EV_INTEGRATE, EV_SORT, EV_BUILD, EV_COM, EV_TRAVERSE, EV_COUNT };
+enum { EV_BEGIN = 0, EV_INTEGRATE, EV_SORT, EV_BUILD, EV_COM, EV_TRAVERSE,
+       EV_TF0_BEGIN, EV_TF0_END, EV_TF1_BEGIN, EV_TF1_END,   // nbody_traverse_from calls of the step
+       EV_COUNT };
 
 struct Float4 { float x, y, z, w; };
 // Traversal record of an octree node.  Leaf: first/count = particle range, meta = NODE_LEAF.
@@ -134,6 +136,7 @@ struct Sim {
     // timing
     hipEvent_t ev[TIMING_RING][EV_COUNT]{};
     int ev_head = 0, ev_pending = 0;
+    int tf_calls[TIMING_RING]{};     // timed nbody_traverse_from calls per recorded step (<= 2)
     uint64_t *inter_dev = nullptr;   // [TIMING_RING] interactions per step
     // validator: all-pairs twin simulation (state in spawn order) + history
     Float4 *tw_posm = nullptr;
@@ -166,7 +169,7 @@ hipError_t launch_twin_kick_drift(int n, float dt, float domain, Float4 *posm, c
 hipError_t launch_vel_kick_raw(int n, float dt, float keep, const float *vhx, const float *vhy,
                                const float *vhz, const float *ax, const float *ay, const float *az,
                                float *vx, float *vy, float *vz, hipStream_t st);
-hipError_t launch_count_interactions(Sim *s, unsigned long long *out);
+hipError_t launch_count_interactions(Sim *s, unsigned long long *out, bool all_groups_add = false);
 hipError_t launch_traverse_from(Sim *bodies, Sim *sources, bool accumulate);
 hipError_t launch_potential(Sim *s);                        // -> s->pot
 hipError_t launch_export_view(Sim *s);                      // positions + node COM/size -> ext[]

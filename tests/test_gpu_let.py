@@ -204,3 +204,27 @@ def test_set_particles_with_head_room_equals_exact_size_handle():
         for k in ("x", "y", "z", "vx", "vy", "vz", "ax", "ay", "az", "id"):
             assert np.array_equal(sa[k], sb[k]), k
         assert a.tree_counts() == b.tree_counts()
+
+
+def test_traverse_from_calls_are_timed_and_counted():
+    """With FLAG_TIMING the step record includes the traversals driven through
+    traverse_from (own tree + imported tree in a domain-decomposed step)."""
+    n = 8192
+    ic = nb.sample_ic(nb.IC_SPHERE, n, 6)
+    p = nb.Params(num_points=n, theta=0.5, dt=1e-3, softening_factor=0.01, morton_bits=21,
+                  domain_size=DOMAIN, flags=nb.FLAG_TIMING)
+    with nb.Simulation(p) as a, nb.Simulation(p) as b:
+        for s in (a, b):
+            s.set_state(ic["x"], ic["y"], ic["z"], ic["m"])
+        a.update()
+        ta = a.get_timings()
+        b.set_traversal_range(0, 0)
+        b.update()                       # build only
+        b.traverse_from(b, accumulate=False)
+        b.finish_step()
+        tb = b.get_timings()
+        sa, sb = a.get_state(), b.get_state()
+    assert tb["steps"] == 1 and tb["interactions"] == ta["interactions"] > 0
+    assert tb["ms_traverse"] > 0 and tb["ms_total"] >= tb["ms_traverse"]
+    for k in ("ax", "vx", "x"):
+        assert np.array_equal(sa[k], sb[k])
