@@ -45,7 +45,7 @@ SUSTAINED_CLOCK_GHZ = 2.0          # shader clock measured inside k_traverse (pr
 REFERENCE_MS_PER_STEP = 150.0      # reference README, RTX 500 Ada, 2,097,152 particles, theta=0.6
 
 
-def cpu_baseline(ic, bits, steps=1):
+def cpu_baseline(ic, bits, steps=1, eps=EPS):
     """The host oracle (same algorithm, same parameters) timed on this machine's cores on
     `steps` steps of the full 2,097,152-particle workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -53,7 +53,7 @@ def cpu_baseline(ic, bits, steps=1):
     cores = O.lib().orc_num_threads()
     t0 = time.time()
     sim = O.OracleSim(ic["x"], ic["y"], ic["z"], ic["m"], bits=bits, max_codes=32, group=64,
-                      theta=THETA, dt=DT, gravity=1.0, eps=EPS, domain=5.0)
+                      theta=THETA, dt=DT, gravity=1.0, eps=eps, domain=5.0)
     spawn_s = time.time() - t0
     ms, inter, tb, tt = [], 0, 0.0, 0.0
     for _ in range(steps):
@@ -143,6 +143,9 @@ def main():
     ap.add_argument("--no-alt-bits", action="store_true",
                     help="skip the short extra run with the other key width")
     ap.add_argument("--particles-per-gpu", type=int, default=N_PER_GPU)
+    ap.add_argument("--ic", choices=["sphere", "plummer"], default="sphere",
+                    help="sphere = the headline workload; plummer = cold Plummer sphere a=0.1, r<=1, "
+                         "total mass 1, eps=1e-3 (16,777,216 particles at --gpus 8)")
     ap.add_argument("--parallelism", choices=["let", "replicated"], default="let",
                     help="multi-GPU scheme (ignored with one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -194,7 +197,12 @@ def main():
     group = 64
     ngroups = (n + group - 1) // group
     let = world > 1 and args.parallelism == "let"
-    ic = nb.sample_ic(nb.IC_SPHERE, n, 42)
+    eps = EPS
+    if args.ic == "plummer":
+        ic = nb.sample_ic(nb.IC_PLUMMER, n, 42, p0=0.1, p1=1.0)
+        eps = 1e-3
+    else:
+        ic = nb.sample_ic(nb.IC_SPHERE, n, 42)
     if let:
         from nbody_amd import parallel
         own = parallel.domain_slices(ic["x"], ic["y"], ic["z"], world)[rank]
@@ -203,7 +211,7 @@ def main():
         assert ngroups % world == 0, "groups must divide evenly over the ranks"
     n_here = len(ic["x"])
     params = nb.Params(num_points=n_here, max_num_codes_per_leaf=32, traversal_group_size=group,
-                       theta=THETA, dt=DT, gravity=1.0, softening_factor=EPS, domain_size=5.0,
+                       theta=THETA, dt=DT, gravity=1.0, softening_factor=eps, domain_size=5.0,
                        morton_bits=args.morton_bits, device_id=local_rank,
                        flags=nb.FLAG_TIMING | (nb.FLAG_DEBUG_WALK_ONLY if args.walk_only else 0))
     sim = nb.Simulation(params)
@@ -352,8 +360,10 @@ def main():
             "vs_baseline": round(ms_step / REFERENCE_MS_PER_STEP, 5) if world == 1 else None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "cold uniform sphere r=0.5 in domain 5.0 (SPAWN_SPHERE), "
-                                   f"{args.particles_per_gpu} particles/GPU, theta=0.6, eps=0.1, "
+            "config": {"workload": ("cold uniform sphere r=0.5 in domain 5.0 (SPAWN_SPHERE), "
+                                    if args.ic == "sphere" else
+                                    "cold Plummer sphere a=0.1 truncated at r=1 in domain 5.0, total mass 1, ") +
+                                   f"{args.particles_per_gpu} particles/GPU, theta=0.6, eps={eps:g}, "
                                    "dt=1e-6, 32 codes/leaf, group=64",
                        "particles": n, "morton_bits": args.morton_bits,
                        "parallelism": "single" if world == 1 else
@@ -407,7 +417,7 @@ def main():
         if alt is not None:
             out["other_key_width"] = alt
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ic, args.morton_bits)
+            out["cpu_baseline"] = cpu_baseline(ic, args.morton_bits, eps=eps)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -6,15 +6,17 @@ import nbody_amd as nb
 from nbody_amd import parallel
 
 world = int(sys.argv[1]); n_per = int(sys.argv[2]); bits = int(sys.argv[3]) if len(sys.argv) > 3 else 21
-leafc = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+leafc = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+kind = sys.argv[5] if len(sys.argv) > 5 else "sphere"
 n = world * n_per
 t0 = time.time()
-ic = nb.sample_ic(nb.IC_SPHERE, n, 42)
+ic = nb.sample_ic(nb.IC_SPHERE, n, 42) if kind == "sphere" else nb.sample_ic(nb.IC_PLUMMER, n, 42, p0=0.1, p1=1.0)
+EPS = 0.1 if kind == "sphere" else 1e-3
 parts = parallel.domain_slices(ic["x"], ic["y"], ic["z"], world)
 print(f"ic+orb {time.time()-t0:.1f}s", flush=True)
 sims, bes = [], []
 for idx in parts:
-    s = nb.Simulation(nb.Params(num_points=len(idx), theta=0.6, dt=1e-6, softening_factor=0.1,
+    s = nb.Simulation(nb.Params(num_points=len(idx), theta=0.6, dt=1e-6, softening_factor=EPS,
                                 morton_bits=bits, flags=nb.FLAG_TIMING))
     s.set_state(ic["x"][idx], ic["y"][idx], ic["z"][idx], ic["m"][idx])
     sims.append(s); bes.append(parallel.GpuLetBackend(s, "cuda:0", remote_codes_per_leaf=leafc))
