@@ -94,9 +94,11 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
     float *lxyf = reinterpret_cast<float *>(L.lxy);
     float *lzmf = reinterpret_cast<float *>(L.lzm);
 
-    const int b = g * G + lane;
+    // G == 32: both half-waves hold the same 32 bodies; the lower half evaluates the even source
+    // pairs of the ring, the upper half the odd ones, and the two partial sums meet at the end.
+    const int b = g * G + (G == 32 ? (lane & 31) : lane);
     const bool active = lane < G && b < n;
-    const Float4 me = body_posm[active ? b : g * G];
+    const Float4 me = body_posm[b < n ? b : g * G];
     if (lane < G) {
         const int p = lane >> 1, h = lane & 1;
         bxyf[4 * p + h] = me.x;
@@ -155,8 +157,14 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
         PROF_T0();
         __builtin_amdgcn_wave_barrier();
         const int hp = head >> 1;
+        if constexpr (G == 32) {
+            const int half = lane >> 5;
 #pragma unroll 8
-        for (int j = 0; j < 32; ++j) pair_force(L.lxy[hp + j], L.lzm[hp + j]);
+            for (int j = 0; j < 16; ++j) pair_force(L.lxy[hp + 2 * j + half], L.lzm[hp + 2 * j + half]);
+        } else {
+#pragma unroll 8
+            for (int j = 0; j < 32; ++j) pair_force(L.lxy[hp + j], L.lzm[hp + j]);
+        }
         head ^= 64;
         list_n -= 64;
         __builtin_amdgcn_wave_barrier();
@@ -203,6 +211,58 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
         const int next_pb = __shfl_down(pb, 1, 64);
         const bool is_head = valid && (lane == 0 || prev_end != pb);
         const bool is_tail = valid && (lane == cnt - 1 || next_pb != pe);
+        if constexpr (G == 32) {
+            // Half-wave split: wave-uniform SGPR sources would make both halves evaluate the
+            // same pairs, so runs are staged through the LDS ring instead, 32 pair records
+            // (1 KB, one 16-byte piece per lane) at a time and always as whole pairs: a run
+            // that starts on the second particle of a pair or ends on the first gets the mass
+            // of the foreign particle replaced by zero on the way in.
+            (void) is_tail;
+            const v4f *P4 = reinterpret_cast<const v4f *>(posm2);
+            unsigned long long hm = __ballot(is_head);
+            PROF_T0();
+            while (hm) {
+                const int h = (int) __builtin_ctzll(hm);
+                hm &= hm - 1;
+                const int t = (hm ? (int) __builtin_ctzll(hm) : cnt) - 1;   // last lane of the run
+                const int rb = __builtin_amdgcn_readlane(pb, h);
+                const int re = __builtin_amdgcn_readlane(pe, t);
+                total += (uint32_t) (re - rb);
+                const int p0 = rb >> 1, p1 = (re + 1) >> 1;                 // pairs [p0, p1)
+                const int pp = lane >> 1, part = lane & 1;
+                auto fetch = [&](int c0) -> v4f {
+                    const int gp = c0 + pp;
+                    v4f d = {0.f, 0.f, 0.f, 0.f};
+                    if (gp < p1) {
+                        d = P4[2 * (size_t) gp + part];
+                        if (part) {
+                            if (gp == p0 && (rb & 1)) d.z = 0.f;
+                            if (gp == p1 - 1 && (re & 1)) d.w = 0.f;
+                        }
+                    }
+                    return d;
+                };
+                v4f data = fetch(p0);
+                for (int c0 = p0; c0 < p1; c0 += 32) {
+                    if (list_n & 1) {   // keep the ring pair-aligned
+                        if (lane == 0) write_entry((head + list_n) & 127, Float4{0.f, 0.f, 0.f, 0.f});
+                        list_n += 1;
+                    }
+                    if (list_n >= 64) flush64();
+                    const int np = min(32, p1 - c0);
+                    const int wp = ((head + list_n) & 127) >> 1;
+                    if (pp < np) {
+                        const int slot = (wp + pp) & 63;
+                        if (part) L.lzm[slot] = data; else L.lxy[slot] = data;
+                    }
+                    list_n += 2 * np;
+                    if (c0 + 32 < p1) data = fetch(c0 + 32);   // in flight during the flush
+                    if (list_n >= 64) flush64();
+                }
+            }
+            PROF_ADD(1);
+            return;
+        }
         // The scalar stream below has one request in flight per wave, so a miss in L2 stalls
         // it for a full memory round trip.  Touch every 128-byte line of this lane's leaf with
         // an ordinary vector load first: all 64 leaves of the batch are then on their way into
@@ -433,9 +493,19 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
     {
         const int hp = head >> 1;
         const int np2 = (list_n + 1) >> 1;
-        for (int j = 0; j < np2; ++j) pair_force(L.lxy[hp + j], L.lzm[hp + j]);
+        if constexpr (G == 32) {
+            const int half = lane >> 5;
+            for (int j = half; j < np2; j += 2) pair_force(L.lxy[hp + j], L.lzm[hp + j]);
+        } else {
+            for (int j = 0; j < np2; ++j) pair_force(L.lxy[hp + j], L.lzm[hp + j]);
+        }
     }
-    const float fx = fx2.x + fx2.y, fy = fy2.x + fy2.y, fz = fz2.x + fz2.y;
+    float fx = fx2.x + fx2.y, fy = fy2.x + fy2.y, fz = fz2.x + fz2.y;
+    if constexpr (G == 32) {   // the other half-wave holds the other half of the sources
+        fx += __shfl_xor(fx, 32, 64);
+        fy += __shfl_xor(fy, 32, 64);
+        fz += __shfl_xor(fz, 32, 64);
+    }
 
 #if NB_WALK_PROFILE
     if (lane == 0) {

@@ -408,3 +408,26 @@ def test_headline_workload_first_step_matches_oracle():
     err = np.sqrt((st["ax"] - ax) ** 2 + (st["ay"] - ay) ** 2 + (st["az"] - az) ** 2)
     ref_n = np.sqrt(ax.astype(np.float64) ** 2 + ay ** 2 + az ** 2)
     assert (err / ref_n).max() < 1e-4 and (err / ref_n).mean() < 1e-5
+
+
+@pytest.mark.parametrize("n,bits,theta", [(1000, 21, 0.5), (33, 10, 0.8), (4097, 21, 0.0)])
+def test_group_of_32_ragged_sizes(n, bits, theta):
+    """traversal_group_size = 32 (the reference renderer's default): one wave64 holds the 32
+    bodies twice and splits the sources between its halves; ragged last group, odd run ends."""
+    ic = make_ic("clusters", n)
+    eps = 0.01
+    with new_sim(n, morton_bits=bits, traversal_group_size=32, theta=theta, dt=1e-3,
+                 softening_factor=eps) as sim:
+        sim.set_state(ic["x"], ic["y"], ic["z"], ic["m"])
+        gpu = sim.get_octree()
+        st0 = sim.get_state()
+        sim.update()                     # v = a = 0: nothing moves, forces of the spawn positions
+        ll = sim.get_octree()["list_len"]
+        st = sim.get_state()
+    ref = O.full_build(st0["x"], st0["y"], st0["z"], st0["m"], 5.0, bits, 32)
+    ax, ay, az, wl = O.traverse(ref["tree"], ref["com"], ref["xs"], ref["ys"], ref["zs"], ref["ms"],
+                                32, theta, eps, 1.0, 5.0)
+    assert np.array_equal(ll, wl)
+    err = np.sqrt((st["ax"] - ax) ** 2 + (st["ay"] - ay) ** 2 + (st["az"] - az) ** 2)
+    ref_n = np.sqrt(ax.astype(np.float64) ** 2 + ay ** 2 + az ** 2)
+    assert (err / np.maximum(ref_n, 1e-30)).max() < 1e-4
