@@ -332,6 +332,23 @@ def main():
                "traversal_ms": round(t2["ms_traverse"] / 20, 4),
                "build_ms": round((t2["ms_integrate"] + t2["ms_sort"] + t2["ms_build"] + t2["ms_com"]) / 20, 4),
                "interactions_per_step": round(t2["interactions"] / 20)}
+    g32 = None
+    if world == 1 and not args.no_alt_bits and not args.walk_only:
+        # the reference renderer's default traversal_group_size (src/renderer.cpp:305), for the record
+        p3 = nb.Params(**{**params.__dict__, "traversal_group_size": 32})
+        with nb.Simulation(p3) as s5:
+            s5.set_state(ic["x"], ic["y"], ic["z"], ic["m"])
+            s5.step(3)
+            s5.get_timings()
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            s5.step(20)
+            s5.sync()
+            tb = time.perf_counter()
+            t5 = s5.get_timings()
+        g32 = {"traversal_group_size": 32, "ms_per_step": round((tb - ta) * 1e3 / 20, 4),
+               "traversal_ms": round(t5["ms_traverse"] / 20, 4),
+               "interactions_per_step": round(t5["interactions"] / 20)}
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
@@ -416,6 +433,8 @@ def main():
             out["after_collapse"] = evolved
         if alt is not None:
             out["other_key_width"] = alt
+        if g32 is not None:
+            out["other_group_size"] = g32
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ic, args.morton_bits, eps=eps)
         print(json.dumps(out))

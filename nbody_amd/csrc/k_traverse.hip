@@ -221,44 +221,56 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
             const v4f *P4 = reinterpret_cast<const v4f *>(posm2);
             unsigned long long hm = __ballot(is_head);
             PROF_T0();
-            while (hm) {
-                const int h = (int) __builtin_ctzll(hm);
-                hm &= hm - 1;
-                const int t = (hm ? (int) __builtin_ctzll(hm) : cnt) - 1;   // last lane of the run
-                const int rb = __builtin_amdgcn_readlane(pb, h);
-                const int re = __builtin_amdgcn_readlane(pe, t);
-                total += (uint32_t) (re - rb);
-                const int p0 = rb >> 1, p1 = (re + 1) >> 1;                 // pairs [p0, p1)
-                const int pp = lane >> 1, part = lane & 1;
-                auto fetch = [&](int c0) -> v4f {
-                    const int gp = c0 + pp;
-                    v4f d = {0.f, 0.f, 0.f, 0.f};
-                    if (gp < p1) {
-                        d = P4[2 * (size_t) gp + part];
-                        if (part) {
-                            if (gp == p0 && (rb & 1)) d.z = 0.f;
-                            if (gp == p1 - 1 && (re & 1)) d.w = 0.f;
-                        }
-                    }
-                    return d;
-                };
-                v4f data = fetch(p0);
-                for (int c0 = p0; c0 < p1; c0 += 32) {
-                    if (list_n & 1) {   // keep the ring pair-aligned
-                        if (lane == 0) write_entry((head + list_n) & 127, Float4{0.f, 0.f, 0.f, 0.f});
-                        list_n += 1;
-                    }
-                    if (list_n >= 64) flush64();
-                    const int np = min(32, p1 - c0);
-                    const int wp = ((head + list_n) & 127) >> 1;
-                    if (pp < np) {
-                        const int slot = (wp + pp) & 63;
-                        if (part) L.lzm[slot] = data; else L.lxy[slot] = data;
-                    }
-                    list_n += 2 * np;
-                    if (c0 + 32 < p1) data = fetch(c0 + 32);   // in flight during the flush
-                    if (list_n >= 64) flush64();
+            // the runs of the batch as one stream of 32-pair pieces; the piece after the one
+            // being evaluated is always in flight, across run boundaries too
+            int rb = 0, re = 0, p0 = 0, p1 = 0, c0 = 0;
+            auto next_run = [&]() -> bool {
+                while (hm) {
+                    const int h = (int) __builtin_ctzll(hm);
+                    hm &= hm - 1;
+                    const int t = (hm ? (int) __builtin_ctzll(hm) : cnt) - 1;   // last lane of the run
+                    rb = __builtin_amdgcn_readlane(pb, h);
+                    re = __builtin_amdgcn_readlane(pe, t);
+                    total += (uint32_t) (re - rb);
+                    p0 = rb >> 1;
+                    p1 = (re + 1) >> 1;                                         // pairs [p0, p1)
+                    c0 = p0;
+                    if (p0 < p1) return true;
                 }
+                return false;
+            };
+            const int pp = lane >> 1, part = lane & 1;
+            auto fetch = [&]() -> v4f {       // this lane's 16 bytes of the piece at c0
+                const int gp = c0 + pp;
+                v4f d = {0.f, 0.f, 0.f, 0.f};
+                if (gp < p1) {
+                    d = P4[2 * (size_t) gp + part];
+                    if (part) {
+                        if (gp == p0 && (rb & 1)) d.z = 0.f;
+                        if (gp == p1 - 1 && (re & 1)) d.w = 0.f;
+                    }
+                }
+                return d;
+            };
+            bool have = next_run();
+            v4f data = {0.f, 0.f, 0.f, 0.f};
+            if (have) data = fetch();
+            while (have) {
+                const int np = min(32, p1 - c0);
+                if (c0 + 32 < p1) c0 += 32; else have = next_run();
+                if (list_n & 1) {   // keep the ring pair-aligned
+                    if (lane == 0) write_entry((head + list_n) & 127, Float4{0.f, 0.f, 0.f, 0.f});
+                    list_n += 1;
+                }
+                if (list_n >= 64) flush64();
+                const int wp = ((head + list_n) & 127) >> 1;
+                if (pp < np) {
+                    const int slot = (wp + pp) & 63;
+                    if (part) L.lzm[slot] = data; else L.lxy[slot] = data;
+                }
+                list_n += 2 * np;
+                if (have) data = fetch();   // in flight during the flush
+                if (list_n >= 64) flush64();
             }
             PROF_ADD(1);
             return;
