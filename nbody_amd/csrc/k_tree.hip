@@ -50,45 +50,62 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_unique(const KeyT *__restrict_
                                                          uint32_t *ticket)
 {
     constexpr int NW = SCAN_THREADS / 64;
+    constexpr int PADDED = SCAN_TILE + SCAN_TILE / SCAN_ITEMS;
     __shared__ uint32_t s_scan[NW + 1];
     __shared__ uint32_t s_bcast[2];
+    // The tile goes through LDS both ways so that global memory only sees consecutive lanes on
+    // consecutive addresses; every SCAN_ITEMS-th slot is padding (a thread's blocked run of
+    // SCAN_ITEMS keys then starts in a different bank from its neighbours').
+    __shared__ KeyT s_k[PADDED];
+    __shared__ int32_t s_i[SCAN_TILE];
+    auto pad = [](int i) { return i + i / SCAN_ITEMS; };
     const int tid = threadIdx.x;
     if (tid == 0) s_bcast[0] = atomicAdd(ticket, 1u);
     __syncthreads();
     const int tile = (int) s_bcast[0];
     const int ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (tile >= ntiles) return;
-    const int base = tile * SCAN_TILE + tid * SCAN_ITEMS;
+    const int tile_base = tile * SCAN_TILE;
+    const int base = tile_base + tid * SCAN_ITEMS;
+    for (int j = tid; j < SCAN_TILE; j += SCAN_THREADS) {
+        const int gi = tile_base + j;
+        s_k[pad(j)] = gi < n ? sorted[gi] : 0;
+    }
+    KeyT prev = 0;
+    if (base > 0 && base <= n) prev = sorted[base - 1];
+    __syncthreads();
 
     KeyT k[SCAN_ITEMS];
     bool f[SCAN_ITEMS];
-    KeyT prev = 0;
-    if (base > 0 && base <= n) prev = sorted[base - 1];
     uint32_t cnt = 0;
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; ++j) {
         const int gi = base + j;
-        k[j] = gi < n ? sorted[gi] : 0;
+        k[j] = s_k[pad(tid * SCAN_ITEMS + j)];
         f[j] = gi < n && (gi == 0 || k[j] != prev);
         prev = k[j];
         cnt += f[j];
     }
     uint32_t tot;
-    const uint32_t excl = block_excl_scan_u32<NW>(cnt, s_scan, &tot);
+    const uint32_t excl = block_excl_scan_u32<NW>(cnt, s_scan, &tot);   // (syncs: s_k is free)
     if (tid < 64) {
         const uint32_t te = lb_exclusive_wave(status, tile, tot, &counts->err);
         if (tid == 0) s_bcast[1] = te;
     }
-    __syncthreads();
-    const uint32_t tile_excl = s_bcast[1];
-    uint32_t pos = tile_excl + excl;
+    uint32_t lp = excl;
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; ++j) {
         if (f[j]) {
-            unique[pos] = k[j];
-            first_pt[pos] = base + j;
-            ++pos;
+            s_k[lp] = k[j];
+            s_i[lp] = base + j;
+            ++lp;
         }
+    }
+    __syncthreads();
+    const uint32_t tile_excl = s_bcast[1];
+    for (uint32_t j = tid; j < tot; j += SCAN_THREADS) {
+        unique[tile_excl + j] = s_k[j];
+        first_pt[tile_excl + j] = s_i[j];
     }
     if (tile == ntiles - 1 && tid == 0) {
         const int U = (int) (tile_excl + tot);
@@ -111,28 +128,32 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_unique(const KeyT *__restrict_
 // Outputs lfc[0..M) (index of each leaf's first code), lfc[M] = U (the sentinel the
 // reference gets from cub::DevicePartition's reversed rear), leaf_key[0..M), M, n_bt.
 // ---------------------------------------------------------------------------
-template <typename KeyT>
-__device__ __forceinline__ bool leaf_head_flag(const KeyT *__restrict__ u, int i, int U,
-                                               int max_codes)
+// `at(j)` returns unique code j (from LDS for indices near the tile, see k_leaves).
+template <typename KeyT, typename At>
+__device__ __forceinline__ bool leaf_head_flag(At at, int i, int U, int max_codes)
 {
     constexpr int KB = KeyBits<KeyT>::KB;
     if (i == 0) return true;
-    const KeyT c = u[i];
-    const int level = lcp_keys(c, u[i - 1]) / 3;
+    const KeyT c = at(i);
+    const int level = lcp_keys(c, at(i - 1)) / 3;
     const int sh = KB - 3 * level;
     const KeyT pre = c >> sh;
     // first code of C is i - left, left in [1, max_codes]; beyond that C is too full anyway
     int lo = 1, hi = min(i, max_codes);
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if ((u[i - mid] >> sh) == pre) lo = mid; else hi = mid - 1;
+        if ((at(i - mid) >> sh) == pre) lo = mid; else hi = mid - 1;
     }
     const int probe = i - lo + max_codes;  // the (max_codes+1)-th code counted from C's start
-    return probe < U && (u[probe] >> sh) == pre;
+    return probe < U && (at(probe) >> sh) == pre;
 }
 
-constexpr int LEAF_ITEMS = 4;
+#ifndef NB_LEAF_ITEMS
+#define NB_LEAF_ITEMS 8
+#endif
+constexpr int LEAF_ITEMS = NB_LEAF_ITEMS;
 constexpr int LEAF_TILE = SCAN_THREADS * LEAF_ITEMS;
+constexpr int LEAF_HALO = 64;   // codes staged on either side of a tile (covers max_codes <= 64)
 
 template <typename KeyT>
 __global__ __launch_bounds__(SCAN_THREADS) void k_leaves(const KeyT *__restrict__ unique,
@@ -144,6 +165,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_leaves(const KeyT *__restrict_
     constexpr int NW = SCAN_THREADS / 64;
     __shared__ uint32_t s_scan[NW + 1];
     __shared__ uint32_t s_bcast[2];
+    __shared__ KeyT s_keys[LEAF_TILE + 2 * LEAF_HALO];
     const int tid = threadIdx.x;
     const int U = counts->U;
     if (tid == 0) s_bcast[0] = atomicAdd(ticket, 1u);
@@ -153,6 +175,19 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_leaves(const KeyT *__restrict_
     if (tile >= ntiles) return;
     const int base = tile * LEAF_TILE + tid * LEAF_ITEMS;
     const bool single = U <= max_codes;  // whole set fits one leaf (undefined in the reference)
+    // The flag of code i looks at codes i - max_codes .. i + max_codes - 1 in a chain of dependent
+    // reads: stage the tile and a halo in LDS so that the chain runs at LDS latency.
+    const int s_lo = tile * LEAF_TILE - LEAF_HALO;
+    for (int j = tid; j < LEAF_TILE + 2 * LEAF_HALO; j += SCAN_THREADS) {
+        const int g = s_lo + j;
+        if (g >= 0 && g < U) s_keys[j] = unique[g];
+    }
+    __syncthreads();
+    const bool staged = max_codes <= LEAF_HALO;
+    auto at = [&](int j) -> KeyT {
+        const int r = j - s_lo;
+        return (staged && r >= 0 && r < LEAF_TILE + 2 * LEAF_HALO) ? s_keys[r] : unique[j];
+    };
 
     bool f[LEAF_ITEMS];
     uint32_t cnt = 0;
@@ -160,7 +195,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_leaves(const KeyT *__restrict_
     for (int j = 0; j < LEAF_ITEMS; ++j) {
         const int i = base + j;
         f[j] = false;
-        if (i < U) f[j] = single ? (i == 0) : leaf_head_flag<KeyT>(unique, i, U, max_codes);
+        if (i < U) f[j] = single ? (i == 0) : leaf_head_flag<KeyT>(at, i, U, max_codes);
         cnt += f[j];
     }
     uint32_t tot;
@@ -176,7 +211,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_leaves(const KeyT *__restrict_
     for (int j = 0; j < LEAF_ITEMS; ++j) {
         if (f[j]) {
             lfc[pos] = base + j;
-            leaf_key[pos] = unique[base + j];
+            leaf_key[pos] = at(base + j);
             ++pos;
         }
     }
