@@ -135,9 +135,16 @@ __device__ __forceinline__ uint32_t lb_exclusive_wave(uint32_t *status, int tile
     return excl;
 }
 
+// All tiles of a launch are resident at once, so inclusive prefixes spread from tile 0 at
+// LB_WINDOW tiles per memory round trip: the window, not the tile count, sets the pace.
+#ifndef NB_LB_WINDOW
+#define NB_LB_WINDOW 8
+#endif
+constexpr int LB_WINDOW = NB_LB_WINDOW;
+
 // Look-back by a single thread for one quantity out of `stride` per tile (used by the radix
 // pass: thread d follows digit d).  The words of the 8 nearest unread predecessors are
-// requested together, so the walk costs one memory round trip per 8 tiles, not per tile.
+// requested together, so the walk costs one memory round trip per LB_WINDOW tiles, not per tile.
 __device__ __forceinline__ uint32_t lb_exclusive_thread(uint32_t *status, int stride, int q,
                                                         int tile, uint32_t aggregate,
                                                         uint32_t *err)
@@ -151,19 +158,19 @@ __device__ __forceinline__ uint32_t lb_exclusive_thread(uint32_t *status, int st
     int t = tile - 1;
     bool done = false;
     while (!done && t >= 0) {
-        uint32_t w[8];
+        uint32_t w[LB_WINDOW];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < LB_WINDOW; ++i)
             w[i] = (t - i >= 0) ? lb_load(&status[(size_t) (t - i) * stride + q]) : LB_PREFIX;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < LB_WINDOW; ++i) {
             if (done) break;
             uint32_t v = w[i];
             if ((v >> 30) == 0u) v = lb_wait(&status[(size_t) (t - i) * stride + q], err);
             excl += v & LB_MASK;
             done = (v >> 30) == 2u;
         }
-        t -= 8;
+        t -= LB_WINDOW;
     }
     lb_store(&status[(size_t) tile * stride + q], LB_PREFIX | (excl + aggregate));
     return excl;

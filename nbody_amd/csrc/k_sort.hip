@@ -17,6 +17,9 @@
 #include "dev_utils.hpp"
 #include "nbody_internal.hpp"
 
+#ifndef NB_HIST_GRID
+#define NB_HIST_GRID 256
+#endif
 namespace nb {
 
 template <typename KeyT, int NPASS>
@@ -26,12 +29,28 @@ __global__ __launch_bounds__(256) void k_sort_hist(const KeyT *__restrict__ keys
     __shared__ uint32_t h[NPASS * 256];
     for (int j = threadIdx.x; j < NPASS * 256; j += 256) h[j] = 0;
     __syncthreads();
-    const int stride = gridDim.x * 256;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const KeyT k = keys[i];
+    // Four consecutive keys per thread: the keys arrive in the previous step's order, so their
+    // upper digits repeat from one key to the next and equal neighbours share one LDS atomic.
+    const int stride = gridDim.x * 256 * 4;
+    for (int i0 = (blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += stride) {
+        KeyT k[4];
 #pragma unroll
-        for (int p = 0; p < NPASS; ++p)
-            atomicAdd(&h[p * 256 + (int) ((k >> (8 * p)) & 255)], 1u);
+        for (int j = 0; j < 4; ++j) k[j] = i0 + j < n ? keys[i0 + j] : keys[i0];
+        const int cntv = min(4, n - i0);
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            int run = 1;
+            int d = (int) ((k[0] >> (8 * p)) & 255);
+#pragma unroll
+            for (int j = 1; j < 4; ++j) {
+                const int dj = (int) ((k[j] >> (8 * p)) & 255);
+                if (j < cntv) {
+                    if (dj == d) ++run;
+                    else { atomicAdd(&h[p * 256 + d], (uint32_t) run); d = dj; run = 1; }
+                }
+            }
+            atomicAdd(&h[p * 256 + d], (uint32_t) run);
+        }
     }
     __syncthreads();
     for (int j = threadIdx.x; j < NPASS * 256; j += 256) {
@@ -163,7 +182,7 @@ static hipError_t sort_impl(Sim *s)
     // layout of the zeroed block: ghist[8*256] | tickets[8] (+pad to 16) | status[P][tiles][256]
     uint32_t *tickets = s->ghist + 8 * 256;
     uint32_t *status = tickets + 16;
-    const int hgrid = std::min(tiles, 256);  // few blocks: the hot bins take one atomic per block
+    const int hgrid = std::min(std::max((n + 4095) / 4096, 1), NB_HIST_GRID);  // few blocks: the hot bins take one atomic per block
     hipLaunchKernelGGL((k_sort_hist<KeyT, NPASS>), dim3(hgrid), dim3(256), 0, s->stream,
                        (const KeyT *) s->keys[0], n, s->ghist);
     int in = 0;

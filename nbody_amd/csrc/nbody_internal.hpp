@@ -11,7 +11,10 @@ namespace nb {
 
 // Work distribution constants shared by host sizing code and kernels.
 constexpr int SORT_THREADS = 256;
-constexpr int SORT_ITEMS = 16;                      // keys per thread per radix tile
+#ifndef NB_SORT_ITEMS
+#define NB_SORT_ITEMS 16
+#endif
+constexpr int SORT_ITEMS = NB_SORT_ITEMS;           // keys per thread per radix tile
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 16;                      // elements per thread in compaction tiles
