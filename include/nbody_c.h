@@ -187,6 +187,10 @@ int nbody_get_octree(nbody_t *sim, nbody_octree_view *host_out);
 
 /* Per-stage device times (ms, HIP events on the handle's stream) summed over the steps
  * run since the last call, and the number of steps summed; needs NBODY_FLAG_TIMING.
+ * Without NBODY_FLAG_TIMING_STAGES only ms_traverse and ms_total are split out and
+ * ms_build holds everything before the traversal.  Traversals driven through
+ * nbody_traverse_from (at most two per step) count into ms_traverse, ms_total and
+ * interactions of the step that precedes them.
  * interactions = sum over those steps of sum_g list_len[g] * bodies_in_group(g). */
 typedef struct nbody_timings {
     int32_t steps;
