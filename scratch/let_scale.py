@@ -51,6 +51,8 @@ for it in range(4):
     T["kick"] = (tick() - t) / world
     sent = [sum(int(v.shape[0]) for v in recs[r].values()) for r in range(world)]
     tm = [s.get_timings() for s in sims]
+    if it == 3:
+        print("per-rank interactions (1e9):", [round(t_["interactions"] / 1e9, 2) for t_ in tm], flush=True)
     print(it, {k: round(v * 1e3, 3) for k, v in T.items()}, "sum_ms", round(sum(T.values()) * 1e3, 3),
           "sent/rank", int(np.mean(sent)), "max", max(sent),
           "own_trav_ms", round(np.mean([t_["ms_traverse"] for t_ in tm]), 3),
