@@ -88,7 +88,8 @@ def test_spawn_build_bit_exact(bits, kind, n, max_codes):
 
 
 @pytest.mark.parametrize("n,bits,max_codes", [(1, 10, 32), (5, 21, 32), (63, 10, 1), (64, 21, 2),
-                                               (65, 10, 32), (200, 21, 1000)])
+                                               (65, 10, 32), (200, 21, 1000), (20000, 21, 100),
+                                               (9000, 21, 64), (9000, 10, 65)])
 def test_tiny_and_single_leaf_cases(n, bits, max_codes):
     ic = make_ic("clusters", n, seed=3)
     with new_sim(n, morton_bits=bits, max_num_codes_per_leaf=max_codes) as sim:
