@@ -105,12 +105,15 @@ def test_let_forces_match_direct_sum_and_single_domain(world):
     assert max_let < 3 * max_one + 5e-2, (max_let, max_one)
 
 
-def test_traverse_from_matches_oracle():
+@pytest.mark.parametrize("group", [64, 32])
+def test_traverse_from_matches_oracle(group):
     """Bodies of one handle against the tree of another: exact list lengths, float tolerance."""
     n, theta, eps = 5000, 0.5, 0.01
     ic = nb.sample_ic(nb.IC_SPHERE, 2 * n, 3)
-    a = nb.Simulation(_params(n, 21, theta, eps))
-    b = nb.Simulation(_params(n, 21, theta, eps))
+    pa = _params(n, 21, theta, eps)
+    pa.traversal_group_size = group
+    a = nb.Simulation(pa)
+    b = nb.Simulation(pa)
     half = lambda k, h: ic[k][h * n:(h + 1) * n]
     # shift the second set so that part of it is far away (approximated nodes) and part overlaps
     a.set_state(half("x", 0), half("y", 0), half("z", 0), half("m", 0))
@@ -120,7 +123,7 @@ def test_traverse_from_matches_oracle():
     ll = a.get_octree()["list_len"]
     tb = O.full_build(sb["x"], sb["y"], sb["z"], sb["m"], DOMAIN, 21, 32)
     wx, wy, wz, wl = O.traverse_from((sa["x"], sa["y"], sa["z"]), tb["tree"], tb["com"], tb["xs"],
-                                     tb["ys"], tb["zs"], tb["ms"], 64, theta, eps, 1.0, DOMAIN)
+                                     tb["ys"], tb["zs"], tb["ms"], group, theta, eps, 1.0, DOMAIN)
     assert np.array_equal(ll, wl)
     for got, want in zip((sa["ax"], sa["ay"], sa["az"]), (wx, wy, wz)):
         scale = np.sqrt(wx.astype(np.float64) ** 2 + wy ** 2 + wz ** 2)
