@@ -43,6 +43,19 @@ enum {
     NBODY_FLAG_TIMING_STAGES = 1u << 2, /* with TIMING: also mark integrate / sort / build / COM
                                           (three more events, a few microseconds each)        */
     NBODY_FLAG_NO_FUSED_VEL = 1u << 1, /* run the velocity half-kick as its own kernel        */
+    NBODY_FLAG_FP64 = 1u << 3,         /* Simulation<double> (reference: src/cuda/simulation.cu:256
+                                          and the `template class X<double>` lines of points.cu:228,
+                                          octree.cu:367, barnes_hut.cu:677, validator.cu:381): the
+                                          handle keeps positions, velocities, masses, accelerations
+                                          and centres of mass in double and runs every
+                                          floating-point stage in double.  The parameters stay
+                                          float, as in the reference (include/simulation.hpp:21-26).
+                                          Every entry point works on such a handle except the
+                                          multi-GPU ones (traversal range, finish_step, bbox,
+                                          let_export, set_sources_dev, traverse_from);
+                                          float arguments are widened and
+                                          float results narrowed, the *_f64 entry points move
+                                          doubles unchanged.                                     */
     NBODY_FLAG_DEBUG_SMALL_STACK = 1u << 9, /* test aid: the traversal runs with a node stack of
                                             32 usable entries, so that its overflow handling
                                             (push-backs, depth-first rounds) is exercised;
@@ -118,6 +131,14 @@ int nbody_sample_ic(int kind, int n, uint64_t seed, float domain_size, float gra
 int nbody_set_state(nbody_t *sim, const float *x, const float *y, const float *z,
                     const float *vx, const float *vy, const float *vz, const float *m);
 
+/* The same with double arrays.  On a handle without NBODY_FLAG_FP64 the values are narrowed;
+ * nbody_set_state() on a handle with it widens. */
+int nbody_set_state_f64(nbody_t *sim, const double *x, const double *y, const double *z,
+                        const double *vx, const double *vy, const double *vz, const double *m);
+int nbody_sample_ic_f64(int kind, int n, uint64_t seed, float domain_size, float gravity, float p0,
+                        float p1, double *x, double *y, double *z, double *vx, double *vy,
+                        double *vz, double *m);
+
 /* Simulation::update()  (include/simulation.hpp:35, src/cuda/simulation.cu:224-238):
  * kick-drift, Morton sort, tree build, traversal, kick.  nbody_step = n updates. */
 int nbody_update(nbody_t *sim);
@@ -146,7 +167,14 @@ int nbody_get_validation_history(nbody_t *sim, double *sys_energy, double *sys_e
 int nbody_get_state(nbody_t *sim, float *x, float *y, float *z, float *vx, float *vy,
                     float *vz, float *m, float *ax, float *ay, float *az, uint32_t *id);
 
-/* Zero-copy device views, valid until the next update/spawn/set_state. */
+/* The same as doubles: exact on a handle with NBODY_FLAG_FP64, widened otherwise. */
+int nbody_get_state_f64(nbody_t *sim, double *x, double *y, double *z, double *vx, double *vy,
+                        double *vz, double *m, double *ax, double *ay, double *az, uint32_t *id);
+
+/* Zero-copy device views, valid until the next update/spawn/set_state.  A handle holds its
+ * arrays in one precision: on a handle with NBODY_FLAG_FP64 the float view has n, id and
+ * stream set and NULL array pointers, and the _f64 view has the arrays; without the flag it
+ * is the other way round. */
 typedef struct nbody_dev_view {
     int32_t n;
     const float *x, *y, *z, *vx, *vy, *vz, *ax, *ay, *az, *m;
@@ -155,6 +183,14 @@ typedef struct nbody_dev_view {
     void *stream;      /* hipStream_t of the handle */
 } nbody_dev_view;
 int nbody_get_device_ptrs(nbody_t *sim, nbody_dev_view *out);
+typedef struct nbody_dev_view_f64 {
+    int32_t n;
+    const double *x, *y, *z, *vx, *vy, *vz, *ax, *ay, *az, *m;
+    const double *posm; /* double4 (x,y,z,m) per particle */
+    const uint32_t *id;
+    void *stream;
+} nbody_dev_view_f64;
+int nbody_get_device_ptrs_f64(nbody_t *sim, nbody_dev_view_f64 *out);
 
 /* Sizes of the last built tree: U unique codes, M leaves, n_oct octree nodes. */
 int nbody_get_tree_counts(nbody_t *sim, int32_t *U, int32_t *M, int32_t *n_oct);
@@ -184,6 +220,9 @@ typedef struct nbody_octree_view {
     uint32_t *list_len;     /* per group: sources interacted with in the last traversal */
 } nbody_octree_view;
 int nbody_get_octree(nbody_t *sim, nbody_octree_view *host_out);
+/* Centres of mass and masses of the n_oct nodes as doubles (exact on a handle with
+ * NBODY_FLAG_FP64, where nbody_octree_view.comx.. are narrowed copies).  Pointers may be NULL. */
+int nbody_get_octree_com_f64(nbody_t *sim, double *comx, double *comy, double *comz, double *mass);
 
 /* Per-stage device times (ms, HIP events on the handle's stream) summed over the steps
  * run since the last call, and the number of steps summed; needs NBODY_FLAG_TIMING.
@@ -216,7 +255,8 @@ int nbody_tree_energy(nbody_t *sim, double *kinetic, double *potential);
  * include/cuda/initial_conditions.cuh).  The file holds x,y,z,vx,vy,vz,m,ax,ay,az and the ids
  * of all particles in the handle's current (sorted) order; a handle with the same parameters
  * that loads it continues bit-identically to the run that saved it.  The validator's all-pairs
- * twin is not part of the file. */
+ * twin is not part of the file.  A handle with NBODY_FLAG_FP64 writes doubles; a file of the
+ * other precision loads with conversion. */
 int nbody_save_snapshot(nbody_t *sim, const char *path);
 int nbody_load_snapshot(nbody_t *sim, const char *path);
 
@@ -229,6 +269,11 @@ int nbody_direct_sum_dev(const float *targets_posm, int32_t nt, const float *sou
                          float *ay, float *az, int32_t accumulate, void *stream);
 /* Direct sum over the handle's own particles (current order); host outputs, n floats each. */
 int nbody_direct_sum(nbody_t *sim, float *ax, float *ay, float *az);
+/* The same evaluated in double (Validator<double>, src/cuda/validator.cu:381): over the double
+ * state of a handle with NBODY_FLAG_FP64; on a float handle over its float positions and
+ * masses widened, which is the accuracy reference for the float tree forces at sizes a host
+ * loop cannot reach. */
+int nbody_direct_sum_f64(nbody_t *sim, double *ax, double *ay, double *az);
 
 /* Multi-GPU sharded traversal: restrict nbody_update()'s traversal to groups
  * [group_begin, group_end) of the sorted order; the caller (one process per GPU) then

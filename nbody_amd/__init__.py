@@ -22,6 +22,7 @@ ERR_CAPACITY = 6
 FLAG_TIMING = 1 << 0
 FLAG_NO_FUSED_VEL = 1 << 1
 FLAG_TIMING_STAGES = 1 << 2
+FLAG_FP64 = 1 << 3
 FLAG_DEBUG_WALK_ONLY = 1 << 8
 FLAG_DEBUG_SMALL_STACK = 1 << 9
 
@@ -84,7 +85,8 @@ EXPORTS = [
     "nbody_direct_sum_dev", "nbody_direct_sum", "nbody_set_traversal_range", "nbody_finish_step",
     "nbody_get_validation_history", "nbody_get_bbox", "nbody_let_export", "nbody_set_sources_dev",
     "nbody_traverse_from", "nbody_save_snapshot", "nbody_load_snapshot", "nbody_set_particles",
-    "nbody_tree_energy",
+    "nbody_tree_energy", "nbody_set_state_f64", "nbody_get_state_f64", "nbody_sample_ic_f64",
+    "nbody_get_octree_com_f64", "nbody_direct_sum_f64", "nbody_get_device_ptrs_f64",
 ]
 
 _lib = None
@@ -149,6 +151,13 @@ def load_library() -> C.CDLL:
                                      C.POINTER(C.c_int32)]
     lib.nbody_set_sources_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     lib.nbody_traverse_from.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    lib.nbody_set_state_f64.argtypes = [C.c_void_p] + [dp] * 7
+    lib.nbody_get_state_f64.argtypes = [C.c_void_p] + [dp] * 10 + [C.POINTER(C.c_uint32)]
+    lib.nbody_sample_ic_f64.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_float, C.c_float, C.c_float,
+                                        C.c_float] + [dp] * 7
+    lib.nbody_get_octree_com_f64.argtypes = [C.c_void_p] + [dp] * 4
+    lib.nbody_direct_sum_f64.argtypes = [C.c_void_p] + [dp] * 3
+    lib.nbody_get_device_ptrs_f64.argtypes = [C.c_void_p, C.POINTER(CDevView)]
     _lib = lib
     return lib
 
@@ -157,13 +166,19 @@ def _fptr(a):
     return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
 
 
+def _dptr(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
 def sample_ic(kind: int, n: int, seed: int = 42, domain_size: float = 5.0, gravity: float = 1.0,
-              p0: float = 0.0, p1: float = 0.0):
-    """Host-side initial-condition sampler of the library: dict of float32 arrays."""
+              p0: float = 0.0, p1: float = 0.0, dtype=np.float32):
+    """Host-side initial-condition sampler of the library: dict of float32 (or float64) arrays."""
     lib = load_library()
-    out = {k: np.empty(n, np.float32) for k in ("x", "y", "z", "vx", "vy", "vz", "m")}
-    rc = lib.nbody_sample_ic(kind, n, seed, domain_size, gravity, p0, p1,
-                             *[_fptr(out[k]) for k in ("x", "y", "z", "vx", "vy", "vz", "m")])
+    f64 = np.dtype(dtype) == np.float64
+    out = {k: np.empty(n, np.float64 if f64 else np.float32) for k in ("x", "y", "z", "vx", "vy", "vz", "m")}
+    fn, ptr = (lib.nbody_sample_ic_f64, _dptr) if f64 else (lib.nbody_sample_ic, _fptr)
+    rc = fn(kind, n, seed, domain_size, gravity, p0, p1,
+            *[ptr(out[k]) for k in ("x", "y", "z", "vx", "vy", "vz", "m")])
     if rc != OK:
         raise RuntimeError(f"nbody_sample_ic failed with status {rc}")
     return out
@@ -194,7 +209,8 @@ class Params:
 
 
 class Simulation:
-    """Headless drop-in for the reference's Simulation<float> (include/simulation.hpp)."""
+    """Headless drop-in for the reference's Simulation<float> (include/simulation.hpp); with
+    FLAG_FP64 in params.flags, for its Simulation<double> (src/cuda/simulation.cu:256)."""
 
     def __init__(self, params: Params, external=None):
         """external: optional 7 device pointers (ints, 0 = skip) [pos.x, pos.y, pos.z, com.x,
@@ -279,17 +295,26 @@ class Simulation:
     def sync(self):
         self._check(self._lib.nbody_sync(self._h))
 
-    def set_state(self, x, y, z, m, vx=None, vy=None, vz=None):
+    @property
+    def fp64(self) -> bool:
+        return bool(self.params.flags & FLAG_FP64)
+
+    def set_state(self, x, y, z, m, vx=None, vy=None, vz=None, dtype=None):
+        """dtype: precision the arrays are handed over in (default: the handle's own)."""
         n = self.params.num_points
+        f64 = self.fp64 if dtype is None else np.dtype(dtype) == np.float64
         arrs = []
         for a in (x, y, z, vx, vy, vz, m):
             if a is None:
                 arrs.append(None)
             else:
-                a = np.ascontiguousarray(a, np.float32)
+                a = np.ascontiguousarray(a, np.float64 if f64 else np.float32)
                 assert a.shape == (n,)
                 arrs.append(a)
-        self._check(self._lib.nbody_set_state(self._h, *[_fptr(a) for a in arrs]))
+        if f64:
+            self._check(self._lib.nbody_set_state_f64(self._h, *[_dptr(a) for a in arrs]))
+        else:
+            self._check(self._lib.nbody_set_state(self._h, *[_fptr(a) for a in arrs]))
 
     def count(self) -> int:
         """Particles currently held (num_points unless set_particles/set_sources changed it)."""
@@ -306,14 +331,16 @@ class Simulation:
             self._h, n, *[_fptr(a) for a in arrs],
             None if ids is None else ids.ctypes.data_as(C.POINTER(C.c_uint32))))
 
-    def get_state(self) -> dict:
+    def get_state(self, dtype=None) -> dict:
+        """dtype: precision of the returned arrays (default: the handle's own)."""
         n = self.count()
+        f64 = self.fp64 if dtype is None else np.dtype(dtype) == np.float64
         names = ("x", "y", "z", "vx", "vy", "vz", "m", "ax", "ay", "az")
-        out = {k: np.empty(n, np.float32) for k in names}
+        out = {k: np.empty(n, np.float64 if f64 else np.float32) for k in names}
         out["id"] = np.empty(n, np.uint32)
-        self._check(self._lib.nbody_get_state(
-            self._h, *[_fptr(out[k]) for k in names],
-            out["id"].ctypes.data_as(C.POINTER(C.c_uint32))))
+        fn, ptr = (self._lib.nbody_get_state_f64, _dptr) if f64 else (self._lib.nbody_get_state, _fptr)
+        self._check(fn(self._h, *[ptr(out[k]) for k in names],
+                       out["id"].ctypes.data_as(C.POINTER(C.c_uint32))))
         return out
 
     def tree_counts(self):
@@ -333,6 +360,11 @@ class Simulation:
             out[k] = np.empty(sizes.get(k, no), dt)
             setattr(view, k, out[k].ctypes.data)
         self._check(self._lib.nbody_get_octree(self._h, C.byref(view)))
+        if self.fp64:   # the exact centres of mass instead of the narrowed copies
+            for k in ("comx", "comy", "comz", "mass"):
+                out[k] = np.empty(no, np.float64)
+            self._check(self._lib.nbody_get_octree_com_f64(
+                self._h, *[_dptr(out[k]) for k in ("comx", "comy", "comz", "mass")]))
         out["U"], out["M"], out["n_oct"] = U, M, no
         return out
 
@@ -346,10 +378,21 @@ class Simulation:
         self._check(self._lib.nbody_get_device_ptrs(self._h, C.byref(v)))
         return v
 
-    def direct_sum(self):
+    def device_view_f64(self) -> CDevView:
+        """The double arrays of a handle with FLAG_FP64 (same field names; posm = double4)."""
+        v = CDevView()
+        self._check(self._lib.nbody_get_device_ptrs_f64(self._h, C.byref(v)))
+        return v
+
+    def direct_sum(self, dtype=None):
+        """dtype float64: the sum evaluated in double (on a float handle over its float state)."""
         n = self.count()
-        out = [np.empty(n, np.float32) for _ in range(3)]
-        self._check(self._lib.nbody_direct_sum(self._h, *[_fptr(a) for a in out]))
+        f64 = self.fp64 if dtype is None else np.dtype(dtype) == np.float64
+        out = [np.empty(n, np.float64 if f64 else np.float32) for _ in range(3)]
+        if f64:
+            self._check(self._lib.nbody_direct_sum_f64(self._h, *[_dptr(a) for a in out]))
+        else:
+            self._check(self._lib.nbody_direct_sum(self._h, *[_fptr(a) for a in out]))
         return out
 
     def set_traversal_range(self, g0: int, g1: int):

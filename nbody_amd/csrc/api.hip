@@ -12,6 +12,7 @@
 #include <cstring>
 #include <fstream>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "nbody_internal.hpp"
@@ -56,6 +57,14 @@ void free_all(Sim *s)
     F(s->nodeA); F(s->nodeB); F(s->list_len); F(s->inter_dev); F(s->trav_tail); F(s->pot);
     F(s->tw_posm); F(s->tw_pot); F(s->ds_pot); F(s->let_boxes); F(s->let_counts);
     for (int k = 0; k < 3; ++k) { F(s->tw_v[k]); F(s->tw_vh[k]); F(s->tw_a[k]); F(s->ds_a[k]); }
+    State64 &d = s->d;
+    for (int i = 0; i < 2; ++i) {
+        F(d.x[i]); F(d.y[i]); F(d.z[i]); F(d.m[i]); F(d.vhx[i]); F(d.vhy[i]); F(d.vhz[i]);
+        F(d.vx[i]); F(d.vy[i]); F(d.vz[i]);
+    }
+    F(d.ax); F(d.ay); F(d.az); F(d.posm); F(d.wsum); F(d.nodeA); F(d.pot); F(d.tw_posm);
+    F(d.tw_pot); F(d.ds_pot);
+    for (int k = 0; k < 3; ++k) { F(d.tw_v[k]); F(d.tw_vh[k]); F(d.tw_a[k]); F(d.ds_a[k]); }
     if (s->counts_host) (void) hipHostFree(s->counts_host);
     for (int r = 0; r < TIMING_RING; ++r)
         for (int k = 0; k < EV_COUNT; ++k)
@@ -63,30 +72,43 @@ void free_all(Sim *s)
     if (s->stream) (void) hipStreamDestroy(s->stream);
 }
 
+// Particle arrays in the handle's precision: R = float uses the Sim members, R = double the
+// State64 ones (same names).
+template <typename R, typename St>
+int alloc_particles(Sim *s, St &a)
+{
+    const size_t n = (size_t) s->cap;
+    for (int i = 0; i < 2; ++i) {
+        R **arr[] = {&a.x[i], &a.y[i], &a.z[i], &a.m[i], &a.vhx[i], &a.vhy[i], &a.vhz[i],
+                     &a.vx[i], &a.vy[i], &a.vz[i]};
+        for (R **q : arr) NB_HIP(s, dalloc(q, n));
+        R *zero[] = {a.vhx[i], a.vhy[i], a.vhz[i], a.vx[i], a.vy[i], a.vz[i]};
+        for (R *q : zero) NB_HIP(s, hipMemsetAsync(q, 0, n * sizeof(R), s->stream));
+    }
+    NB_HIP(s, dalloc(&a.ax, n)); NB_HIP(s, dalloc(&a.ay, n)); NB_HIP(s, dalloc(&a.az, n));
+    NB_HIP(s, dalloc(&a.posm, n));
+    return NBODY_OK;
+}
+
 int alloc_all(Sim *s)
 {
     const size_t n = (size_t) s->cap;
     for (int i = 0; i < 2; ++i) {
-        NB_HIP(s, dalloc(&s->x[i], n)); NB_HIP(s, dalloc(&s->y[i], n)); NB_HIP(s, dalloc(&s->z[i], n));
-        NB_HIP(s, dalloc(&s->m[i], n));
-        NB_HIP(s, dalloc(&s->vhx[i], n)); NB_HIP(s, dalloc(&s->vhy[i], n)); NB_HIP(s, dalloc(&s->vhz[i], n));
-        NB_HIP(s, dalloc(&s->vx[i], n)); NB_HIP(s, dalloc(&s->vy[i], n)); NB_HIP(s, dalloc(&s->vz[i], n));
         NB_HIP(s, dalloc(&s->id[i], n));
         NB_HIP(s, hipMalloc(&s->keys[i], n * s->key_bytes));
         NB_HIP(s, dalloc(&s->vals[i], n));
-        NB_HIP(s, hipMemsetAsync(s->vhx[i], 0, n * 4, s->stream));
-        NB_HIP(s, hipMemsetAsync(s->vhy[i], 0, n * 4, s->stream));
-        NB_HIP(s, hipMemsetAsync(s->vhz[i], 0, n * 4, s->stream));
-        NB_HIP(s, hipMemsetAsync(s->vx[i], 0, n * 4, s->stream));
-        NB_HIP(s, hipMemsetAsync(s->vy[i], 0, n * 4, s->stream));
-        NB_HIP(s, hipMemsetAsync(s->vz[i], 0, n * 4, s->stream));
     }
-    NB_HIP(s, dalloc(&s->ax, n)); NB_HIP(s, dalloc(&s->ay, n)); NB_HIP(s, dalloc(&s->az, n));
-    NB_HIP(s, dalloc(&s->posm, n));
-    // pair records are read two at a time (64 bytes): pad to a whole number of those
-    const size_t posm2_floats = 16 * ((n + 3) / 4);
-    NB_HIP(s, dalloc(&s->posm2, posm2_floats));
-    NB_HIP(s, hipMemsetAsync(s->posm2, 0, posm2_floats * 4, s->stream));
+    if (s->fp64) {
+        int rc = alloc_particles<double>(s, s->d);
+        if (rc) return rc;
+    } else {
+        int rc = alloc_particles<float>(s, *s);
+        if (rc) return rc;
+        // pair records are read two at a time (64 bytes): pad to a whole number of those
+        const size_t posm2_floats = 16 * ((n + 3) / 4);
+        NB_HIP(s, dalloc(&s->posm2, posm2_floats));
+        NB_HIP(s, hipMemsetAsync(s->posm2, 0, posm2_floats * 4, s->stream));
+    }
 
     // sort scratch: ghist[8*256] | tickets[16] | status[P][tiles][256]
     s->sort_tiles = (int) ((n + SORT_TILE - 1) / SORT_TILE);
@@ -125,12 +147,16 @@ int alloc_all(Sim *s)
     NB_HIP(s, dalloc(&s->o_lb, 2 * n)); NB_HIP(s, dalloc(&s->o_le, 2 * n));
     NB_HIP(s, dalloc(&s->o_level, 2 * n)); NB_HIP(s, dalloc(&s->o_pb, 2 * n));
     NB_HIP(s, dalloc(&s->o_pe, 2 * n)); NB_HIP(s, dalloc(&s->o_parent, 2 * n));
-    NB_HIP(s, dalloc(&s->o_size, 2 * n)); NB_HIP(s, dalloc(&s->o_wsum, 2 * n));
-    NB_HIP(s, dalloc(&s->nodeA, 2 * n)); NB_HIP(s, dalloc(&s->nodeB, 2 * n));
+    NB_HIP(s, dalloc(&s->o_size, 2 * n)); NB_HIP(s, dalloc(&s->nodeB, 2 * n));
+    if (s->fp64) {
+        NB_HIP(s, dalloc(&s->d.wsum, 2 * n)); NB_HIP(s, dalloc(&s->d.nodeA, 2 * n));
+    } else {
+        NB_HIP(s, dalloc(&s->o_wsum, 2 * n)); NB_HIP(s, dalloc(&s->nodeA, 2 * n));
+    }
     const size_t ngroups = (n + s->group - 1) / s->group;
     NB_HIP(s, dalloc(&s->list_len, ngroups));
     NB_HIP(s, hipMemsetAsync(s->list_len, 0, std::max<size_t>(ngroups, 1) * 4, s->stream));
-    {
+    if (!s->fp64) {
         TravTail t{};
         t.ax = s->ax; t.ay = s->ay; t.az = s->az;
         t.list_len = s->list_len;
@@ -146,7 +172,15 @@ int alloc_all(Sim *s)
     NB_HIP(s, dalloc(&s->let_counts, (size_t) LET_MAX_BOXES + 8));
     NB_HIP(s, dalloc(&s->inter_dev, (size_t) TIMING_RING));
     NB_HIP(s, hipMemsetAsync(s->inter_dev, 0, TIMING_RING * 8, s->stream));
-    if (s->p.num_steps_validator > 0) {
+    if (s->p.num_steps_validator > 0 && s->fp64) {
+        State64 &d = s->d;
+        NB_HIP(s, dalloc(&d.tw_posm, n)); NB_HIP(s, dalloc(&d.tw_pot, n));
+        NB_HIP(s, dalloc(&d.ds_pot, n));
+        for (int k = 0; k < 3; ++k) {
+            NB_HIP(s, dalloc(&d.tw_v[k], n)); NB_HIP(s, dalloc(&d.tw_vh[k], n));
+            NB_HIP(s, dalloc(&d.tw_a[k], n)); NB_HIP(s, dalloc(&d.ds_a[k], n));
+        }
+    } else if (s->p.num_steps_validator > 0) {
         NB_HIP(s, dalloc(&s->tw_posm, n)); NB_HIP(s, dalloc(&s->tw_pot, n));
         NB_HIP(s, dalloc(&s->ds_pot, n));
         for (int k = 0; k < 3; ++k) {
@@ -185,11 +219,13 @@ inline double normal(uint64_t seed, uint64_t i, uint64_t k, double mean, double 
     return r * std::cos(th) * sd + mean;
 }
 
+// R = float or double: the samples are drawn in double and stored in the handle's precision.
+template <typename R>
 int sample_ic(int kind, int n, uint64_t seed, float domain, float gravity, float p0, float p1,
-              float *x, float *y, float *z, float *vx, float *vy, float *vz, float *m)
+              R *x, R *y, R *z, R *vx, R *vy, R *vz, R *m)
 {
     const double c = domain * 0.5;
-    auto clampd = [&](double v) { return (float) std::max(0.0, std::min((double) domain, v)); };
+    auto clampd = [&](double v) { return (R) std::max(0.0, std::min((double) domain, v)); };
     for (int i = 0; i < n; ++i) {
         double px = c, py = c, pz = c, ux = 0, uy = 0, uz = 0, mass = 1.0;
         switch (kind) {
@@ -245,10 +281,10 @@ int sample_ic(int kind, int n, uint64_t seed, float domain, float gravity, float
         default: return NBODY_ERR_INVALID;
         }
         x[i] = clampd(px); y[i] = clampd(py); z[i] = clampd(pz);
-        if (vx) vx[i] = (float) ux;
-        if (vy) vy[i] = (float) uy;
-        if (vz) vz[i] = (float) uz;
-        m[i] = (float) mass;
+        if (vx) vx[i] = (R) ux;
+        if (vy) vy[i] = (R) uy;
+        if (vz) vz[i] = (R) uz;
+        m[i] = (R) mass;
     }
     return NBODY_OK;
 }
@@ -276,7 +312,7 @@ int fetch_counts(Sim *s)
 int build_after_encode(Sim *s, bool permute_all)
 {
     NB_HIP(s, launch_sort(s));
-    NB_HIP(s, launch_permute(s, permute_all));
+    NB_HIP(s, s->fp64 ? launch64_permute(s, permute_all) : launch_permute(s, permute_all));
     return NBODY_OK;
 }
 
@@ -284,15 +320,22 @@ int build_after_encode(Sim *s, bool permute_all)
 int post_spawn(Sim *s)
 {
     const size_t n = (size_t) s->n;
-    NB_HIP(s, hipMemsetAsync(s->ax, 0, n * 4, s->stream));
-    NB_HIP(s, hipMemsetAsync(s->ay, 0, n * 4, s->stream));
-    NB_HIP(s, hipMemsetAsync(s->az, 0, n * 4, s->stream));
-    NB_HIP(s, launch_morton_only(s));
+    if (s->fp64) {
+        NB_HIP(s, hipMemsetAsync(s->d.ax, 0, n * 8, s->stream));
+        NB_HIP(s, hipMemsetAsync(s->d.ay, 0, n * 8, s->stream));
+        NB_HIP(s, hipMemsetAsync(s->d.az, 0, n * 8, s->stream));
+        NB_HIP(s, launch64_morton_only(s));
+    } else {
+        NB_HIP(s, hipMemsetAsync(s->ax, 0, n * 4, s->stream));
+        NB_HIP(s, hipMemsetAsync(s->ay, 0, n * 4, s->stream));
+        NB_HIP(s, hipMemsetAsync(s->az, 0, n * 4, s->stream));
+        NB_HIP(s, launch_morton_only(s));
+    }
     int rc = build_after_encode(s, true);
     if (rc) return rc;
     NB_HIP(s, launch_build(s));
-    NB_HIP(s, launch_com(s));
-    NB_HIP(s, launch_export_view(s));
+    NB_HIP(s, s->fp64 ? launch64_com(s) : launch_com(s));
+    NB_HIP(s, s->fp64 ? launch64_export_view(s) : launch_export_view(s));
     s->spawned = true;
     s->pending_vel = false;
     s->ev_pending = 0;
@@ -301,41 +344,43 @@ int post_spawn(Sim *s)
     return fetch_counts(s);
 }
 
-int upload_state(Sim *s, const float *x, const float *y, const float *z, const float *vx,
-                 const float *vy, const float *vz, const float *m, int count = -1)
+// Host arrays in the handle's own precision R (St = Sim for float, State64 for double).
+template <typename R, typename St, typename R4>
+int upload_state_r(Sim *s, St &a, R4 *tw_posm, R *const tw_v[3], R *const tw_a[3], const R *x,
+                   const R *y, const R *z, const R *vx, const R *vy, const R *vz, const R *m,
+                   int count)
 {
     s->n = count < 0 ? s->cap : count;
-    const size_t n = (size_t) s->n, b = n * 4;
+    const size_t n = (size_t) s->n, b = n * sizeof(R);
     const int c = s->cur;
     std::vector<uint32_t> ids(n);
     for (size_t i = 0; i < n; ++i) ids[i] = (uint32_t) i;
-    NB_HIP(s, hipMemcpyAsync(s->x[c], x, b, hipMemcpyHostToDevice, s->stream));
-    NB_HIP(s, hipMemcpyAsync(s->y[c], y, b, hipMemcpyHostToDevice, s->stream));
-    NB_HIP(s, hipMemcpyAsync(s->z[c], z, b, hipMemcpyHostToDevice, s->stream));
-    NB_HIP(s, hipMemcpyAsync(s->m[c], m, b, hipMemcpyHostToDevice, s->stream));
-    if (vx) NB_HIP(s, hipMemcpyAsync(s->vx[c], vx, b, hipMemcpyHostToDevice, s->stream));
-    else NB_HIP(s, hipMemsetAsync(s->vx[c], 0, b, s->stream));
-    if (vy) NB_HIP(s, hipMemcpyAsync(s->vy[c], vy, b, hipMemcpyHostToDevice, s->stream));
-    else NB_HIP(s, hipMemsetAsync(s->vy[c], 0, b, s->stream));
-    if (vz) NB_HIP(s, hipMemcpyAsync(s->vz[c], vz, b, hipMemcpyHostToDevice, s->stream));
-    else NB_HIP(s, hipMemsetAsync(s->vz[c], 0, b, s->stream));
-    NB_HIP(s, hipMemsetAsync(s->vhx[c], 0, b, s->stream));
-    NB_HIP(s, hipMemsetAsync(s->vhy[c], 0, b, s->stream));
-    NB_HIP(s, hipMemsetAsync(s->vhz[c], 0, b, s->stream));
-    NB_HIP(s, hipMemcpyAsync(s->id[c], ids.data(), b, hipMemcpyHostToDevice, s->stream));
-    std::vector<Float4> tw;
+    NB_HIP(s, hipMemcpyAsync(a.x[c], x, b, hipMemcpyHostToDevice, s->stream));
+    NB_HIP(s, hipMemcpyAsync(a.y[c], y, b, hipMemcpyHostToDevice, s->stream));
+    NB_HIP(s, hipMemcpyAsync(a.z[c], z, b, hipMemcpyHostToDevice, s->stream));
+    NB_HIP(s, hipMemcpyAsync(a.m[c], m, b, hipMemcpyHostToDevice, s->stream));
+    if (vx) NB_HIP(s, hipMemcpyAsync(a.vx[c], vx, b, hipMemcpyHostToDevice, s->stream));
+    else NB_HIP(s, hipMemsetAsync(a.vx[c], 0, b, s->stream));
+    if (vy) NB_HIP(s, hipMemcpyAsync(a.vy[c], vy, b, hipMemcpyHostToDevice, s->stream));
+    else NB_HIP(s, hipMemsetAsync(a.vy[c], 0, b, s->stream));
+    if (vz) NB_HIP(s, hipMemcpyAsync(a.vz[c], vz, b, hipMemcpyHostToDevice, s->stream));
+    else NB_HIP(s, hipMemsetAsync(a.vz[c], 0, b, s->stream));
+    NB_HIP(s, hipMemsetAsync(a.vhx[c], 0, b, s->stream));
+    NB_HIP(s, hipMemsetAsync(a.vhy[c], 0, b, s->stream));
+    NB_HIP(s, hipMemsetAsync(a.vhz[c], 0, b, s->stream));
+    NB_HIP(s, hipMemcpyAsync(s->id[c], ids.data(), n * 4, hipMemcpyHostToDevice, s->stream));
+    std::vector<R4> tw;
     if (s->p.num_steps_validator > 0) {
         // Validator::copy_initial_conditions (src/cuda/validator.cu:226-236): the all-pairs
         // twin starts from the same particles, zero accelerations; it keeps spawn order.
         tw.resize(n);
-        for (size_t i = 0; i < n; ++i) tw[i] = Float4{x[i], y[i], z[i], m[i]};
-        NB_HIP(s, hipMemcpyAsync(s->tw_posm, tw.data(), n * sizeof(Float4), hipMemcpyHostToDevice,
-                                 s->stream));
-        const float *vsrc[3] = {vx, vy, vz};
+        for (size_t i = 0; i < n; ++i) tw[i] = R4{x[i], y[i], z[i], m[i]};
+        NB_HIP(s, hipMemcpyAsync(tw_posm, tw.data(), n * sizeof(R4), hipMemcpyHostToDevice, s->stream));
+        const R *vsrc[3] = {vx, vy, vz};
         for (int k = 0; k < 3; ++k) {
-            if (vsrc[k]) NB_HIP(s, hipMemcpyAsync(s->tw_v[k], vsrc[k], b, hipMemcpyHostToDevice, s->stream));
-            else NB_HIP(s, hipMemsetAsync(s->tw_v[k], 0, b, s->stream));
-            NB_HIP(s, hipMemsetAsync(s->tw_a[k], 0, b, s->stream));
+            if (vsrc[k]) NB_HIP(s, hipMemcpyAsync(tw_v[k], vsrc[k], b, hipMemcpyHostToDevice, s->stream));
+            else NB_HIP(s, hipMemsetAsync(tw_v[k], 0, b, s->stream));
+            NB_HIP(s, hipMemsetAsync(tw_a[k], 0, b, s->stream));
         }
         s->val_step = 0;
     }
@@ -343,16 +388,46 @@ int upload_state(Sim *s, const float *x, const float *y, const float *z, const f
     return post_spawn(s);
 }
 
+// Host arrays of type In into a handle of either precision (converted on the host when the
+// two differ).
+template <typename In>
+int upload_state(Sim *s, const In *x, const In *y, const In *z, const In *vx, const In *vy,
+                 const In *vz, const In *m, int count = -1)
+{
+    constexpr bool in64 = sizeof(In) == 8;
+    if (in64 == s->fp64) {
+        if constexpr (in64)
+            return upload_state_r<double>(s, s->d, s->d.tw_posm, s->d.tw_v, s->d.tw_a, x, y, z, vx, vy, vz, m, count);
+        else
+            return upload_state_r<float>(s, *s, s->tw_posm, s->tw_v, s->tw_a, x, y, z, vx, vy, vz, m, count);
+    }
+    using Out = std::conditional_t<in64, float, double>;
+    const size_t n = (size_t) (count < 0 ? s->cap : count);
+    std::vector<Out> c[7];
+    const In *src[7] = {x, y, z, vx, vy, vz, m};
+    for (int k = 0; k < 7; ++k)
+        if (src[k]) { c[k].resize(n); for (size_t i = 0; i < n; ++i) c[k][i] = (Out) src[k][i]; }
+    auto P = [&](int k) -> const Out * { return src[k] ? c[k].data() : nullptr; };
+    return upload_state<Out>(s, P(0), P(1), P(2), P(3), P(4), P(5), P(6), count);
+}
+
 int spawn(Sim *s, int kind, float p0, float p1)
 {
     s->n = s->cap;
     const size_t n = (size_t) s->n;
+    if (s->fp64) {
+        std::vector<double> x(n), y(n), z(n), vx(n), vy(n), vz(n), m(n);
+        int rc = sample_ic<double>(kind, s->n, s->p.seed, s->p.domain_size, s->p.gravity, p0, p1,
+                                   x.data(), y.data(), z.data(), vx.data(), vy.data(), vz.data(), m.data());
+        if (rc) return fail(s, rc, "unknown initial condition kind");
+        return upload_state<double>(s, x.data(), y.data(), z.data(), vx.data(), vy.data(), vz.data(), m.data());
+    }
     std::vector<float> x(n), y(n), z(n), vx(n), vy(n), vz(n), m(n);
-    int rc = sample_ic(kind, s->n, s->p.seed, s->p.domain_size, s->p.gravity, p0, p1, x.data(),
-                       y.data(), z.data(), vx.data(), vy.data(), vz.data(), m.data());
+    int rc = sample_ic<float>(kind, s->n, s->p.seed, s->p.domain_size, s->p.gravity, p0, p1, x.data(),
+                              y.data(), z.data(), vx.data(), vy.data(), vz.data(), m.data());
     if (rc) return fail(s, rc, "unknown initial condition kind");
-    return upload_state(s, x.data(), y.data(), z.data(), vx.data(), vy.data(), vz.data(),
-                        m.data());
+    return upload_state<float>(s, x.data(), y.data(), z.data(), vx.data(), vy.data(), vz.data(),
+                               m.data());
 }
 
 // One validator record (reference: Validator<T>::update_all_pairs, src/cuda/validator.cu:238-320,
@@ -416,25 +491,80 @@ int validator_step(Sim *s)
     return NBODY_OK;
 }
 
+// The same record for a double-precision handle: tree run, twin and direct sum all in double
+// (Validator<double>, src/cuda/validator.cu:381).
+int validator_step64(Sim *s)
+{
+    State64 &d = s->d;
+    const int n = s->n;
+    const size_t b = (size_t) n * 8;
+    const int c = s->cur;
+    const double eps = (double) s->p.softening_factor, eps2 = eps * eps;
+    const double G = (double) s->p.gravity, dt = (double) s->p.dt;
+    NB_HIP(s, launch64_direct(d.posm, n, d.posm, n, eps2, G, d.ds_a[0], d.ds_a[1], d.ds_a[2], d.ds_pot, 1, s->stream));
+    NB_HIP(s, launch64_twin_kick_drift(n, dt, (double) s->p.domain_size, d.tw_posm, d.tw_v, d.tw_a, d.tw_vh, s->stream));
+    NB_HIP(s, launch64_direct(d.tw_posm, n, d.tw_posm, n, eps2, G, d.tw_a[0], d.tw_a[1], d.tw_a[2], d.tw_pot, 1, s->stream));
+    NB_HIP(s, launch64_vel_kick_raw(n, dt, 1.0 - (double) s->p.velocity_dampening, d.tw_vh, d.tw_a, d.tw_v, s->stream));
+    std::vector<double> a[3], ds[3], v[3], tv[3], pot(n), tpot(n), m(n);
+    std::vector<Double4> tp(n);
+    const double *acc[3] = {d.ax, d.ay, d.az};
+    const double *vel[3] = {d.vx[c], d.vy[c], d.vz[c]};
+    for (int k = 0; k < 3; ++k) {
+        a[k].resize(n); ds[k].resize(n); v[k].resize(n); tv[k].resize(n);
+        NB_HIP(s, hipMemcpyAsync(a[k].data(), acc[k], b, hipMemcpyDeviceToHost, s->stream));
+        NB_HIP(s, hipMemcpyAsync(ds[k].data(), d.ds_a[k], b, hipMemcpyDeviceToHost, s->stream));
+        NB_HIP(s, hipMemcpyAsync(v[k].data(), vel[k], b, hipMemcpyDeviceToHost, s->stream));
+        NB_HIP(s, hipMemcpyAsync(tv[k].data(), d.tw_v[k], b, hipMemcpyDeviceToHost, s->stream));
+    }
+    NB_HIP(s, hipMemcpyAsync(pot.data(), d.ds_pot, b, hipMemcpyDeviceToHost, s->stream));
+    NB_HIP(s, hipMemcpyAsync(tpot.data(), d.tw_pot, b, hipMemcpyDeviceToHost, s->stream));
+    NB_HIP(s, hipMemcpyAsync(m.data(), d.m[c], b, hipMemcpyDeviceToHost, s->stream));
+    NB_HIP(s, hipMemcpyAsync(tp.data(), d.tw_posm, (size_t) n * sizeof(Double4), hipMemcpyDeviceToHost, s->stream));
+    NB_HIP(s, hipStreamSynchronize(s->stream));
+    double e = 0, e_ap = 0, err = 0;
+    for (int i = 0; i < n; ++i) {
+        e += m[i] * (0.5 * (v[0][i] * v[0][i] + v[1][i] * v[1][i] + v[2][i] * v[2][i]) - 0.5 * G * pot[i]);
+        e_ap += tp[i].w * (0.5 * (tv[0][i] * tv[0][i] + tv[1][i] * tv[1][i] + tv[2][i] * tv[2][i]) - 0.5 * G * tpot[i]);
+        const double dx = a[0][i] - ds[0][i], dy = a[1][i] - ds[1][i], dz = a[2][i] - ds[2][i];
+        const double dn = std::sqrt(ds[0][i] * ds[0][i] + ds[1][i] * ds[1][i] + ds[2][i] * ds[2][i]);
+        if (dn > 0) err += std::sqrt(dx * dx + dy * dy + dz * dz) / dn;
+    }
+    const size_t cap = (size_t) s->p.num_steps_validator;
+    if (s->hist_e.size() < cap) { s->hist_e.resize(cap); s->hist_e_ap.resize(cap); s->hist_err.resize(cap); }
+    s->hist_e[s->val_step] = e;
+    s->hist_e_ap[s->val_step] = e_ap;
+    s->hist_err[s->val_step] = err / n;
+    s->val_step = (s->val_step + 1) % s->p.num_steps_validator;
+    if (s->val_count < (int) cap) s->val_count++;
+    return NBODY_OK;
+}
+
 // upload_state + accelerations and ids carried through the sort it performs (identity when
 // the particles arrive in the sorted order of a previous step).
-int set_particles(Sim *s, int count, const float *x, const float *y, const float *z, const float *vx,
-                  const float *vy, const float *vz, const float *m, const float *ax, const float *ay,
-                  const float *az, const uint32_t *id)
+template <typename R>
+int set_particles(Sim *s, int count, const R *x, const R *y, const R *z, const R *vx, const R *vy,
+                  const R *vz, const R *m, const R *ax, const R *ay, const R *az, const uint32_t *id)
 {
-    int rc = upload_state(s, x, y, z, vx, vy, vz, m, count);
+    int rc = upload_state<R>(s, x, y, z, vx, vy, vz, m, count);
     if (rc) return rc;
     if (!ax && !ay && !az && !id) return NBODY_OK;
     const size_t n = (size_t) count;
     std::vector<uint32_t> perm(n), nid(n);
     NB_HIP(s, hipMemcpy(perm.data(), s->id[s->cur], n * 4, hipMemcpyDeviceToHost));
-    std::vector<float> a(n);
-    const float *src[3] = {ax, ay, az};
-    float *dst[3] = {s->ax, s->ay, s->az};
+    const R *src[3] = {ax, ay, az};
     for (int k = 0; k < 3; ++k) {
         if (!src[k]) continue;
-        for (size_t i = 0; i < n; ++i) a[i] = src[k][perm[i]];
-        NB_HIP(s, hipMemcpy(dst[k], a.data(), n * 4, hipMemcpyHostToDevice));
+        if (s->fp64) {
+            std::vector<double> a(n);
+            double *dst[3] = {s->d.ax, s->d.ay, s->d.az};
+            for (size_t i = 0; i < n; ++i) a[i] = (double) src[k][perm[i]];
+            NB_HIP(s, hipMemcpy(dst[k], a.data(), n * 8, hipMemcpyHostToDevice));
+        } else {
+            std::vector<float> a(n);
+            float *dst[3] = {s->ax, s->ay, s->az};
+            for (size_t i = 0; i < n; ++i) a[i] = (float) src[k][perm[i]];
+            NB_HIP(s, hipMemcpy(dst[k], a.data(), n * 4, hipMemcpyHostToDevice));
+        }
     }
     if (id) {
         for (size_t i = 0; i < n; ++i) nid[i] = id[perm[i]];
@@ -442,6 +572,69 @@ int set_particles(Sim *s, int count, const float *x, const float *y, const float
     }
     return NBODY_OK;
 }
+
+// Device array of the handle's precision Src copied out to a host array of type Dst.
+template <typename Dst, typename Src>
+hipError_t copy_out(Sim *s, Dst *dst, const Src *src, size_t n)
+{
+    if (!dst) return hipSuccess;
+    if constexpr (std::is_same<Dst, Src>::value) {
+        return hipMemcpyAsync(dst, src, n * sizeof(Src), hipMemcpyDeviceToHost, s->stream);
+    } else {
+        std::vector<Src> tmp(n);
+        hipError_t e = hipMemcpyAsync(tmp.data(), src, n * sizeof(Src), hipMemcpyDeviceToHost, s->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+        for (size_t i = 0; i < n; ++i) dst[i] = (Dst) tmp[i];
+        return e;
+    }
+}
+
+template <typename Dst>
+int get_state(Sim *s, Dst *x, Dst *y, Dst *z, Dst *vx, Dst *vy, Dst *vz, Dst *m, Dst *ax, Dst *ay,
+              Dst *az, uint32_t *id)
+{
+    const size_t n = (size_t) s->n;
+    const int c = s->cur;
+    if (s->fp64) {
+        const State64 &d = s->d;
+        Dst *dst[10] = {x, y, z, vx, vy, vz, m, ax, ay, az};
+        const double *src[10] = {d.x[c], d.y[c], d.z[c], d.vx[c], d.vy[c], d.vz[c], d.m[c], d.ax, d.ay, d.az};
+        for (int k = 0; k < 10; ++k) NB_HIP(s, copy_out(s, dst[k], src[k], n));
+    } else {
+        Dst *dst[10] = {x, y, z, vx, vy, vz, m, ax, ay, az};
+        const float *src[10] = {s->x[c], s->y[c], s->z[c], s->vx[c], s->vy[c], s->vz[c], s->m[c], s->ax, s->ay, s->az};
+        for (int k = 0; k < 10; ++k) NB_HIP(s, copy_out(s, dst[k], src[k], n));
+    }
+    NB_HIP(s, copy_out(s, id, s->id[c], n));
+    return NBODY_OK;
+}
+
+// Centres of mass and masses of the first `no` octree nodes as host arrays of type Dst.
+template <typename Dst>
+int get_com(Sim *s, size_t no, Dst *comx, Dst *comy, Dst *comz, Dst *mass)
+{
+    auto spread = [&](auto &a) {
+        for (size_t i = 0; i < no; ++i) {
+            if (comx) comx[i] = (Dst) a[i].x;
+            if (comy) comy[i] = (Dst) a[i].y;
+            if (comz) comz[i] = (Dst) a[i].z;
+            if (mass) mass[i] = (Dst) a[i].w;
+        }
+    };
+    if (s->fp64) {
+        std::vector<Double4> a(no);
+        NB_HIP(s, hipMemcpy(a.data(), s->d.nodeA, no * sizeof(Double4), hipMemcpyDeviceToHost));
+        spread(a);
+    } else {
+        std::vector<Float4> a(no);
+        NB_HIP(s, hipMemcpy(a.data(), s->nodeA, no * sizeof(Float4), hipMemcpyDeviceToHost));
+        spread(a);
+    }
+    return NBODY_OK;
+}
+
+#define NB_FLOAT_ONLY(s, what)                                                                 \
+    if ((s)->fp64) return fail(s, NBODY_ERR_STATE, what ": not available on a double-precision handle")
 
 struct DevGuard {
     int prev = -1;
@@ -479,8 +672,9 @@ int nbody_create_external(const nbody_params *params, void *dev_ptrs[7], nbody_t
     if (rc != NBODY_OK || !dev_ptrs) return rc;
     Sim *s = reinterpret_cast<Sim *>(*out);
     for (int i = 0; i < 7; ++i) {
-        s->ext[i] = static_cast<float *>(dev_ptrs[i]);
-        s->has_ext = s->has_ext || s->ext[i] != nullptr;
+        if (s->fp64) s->d.ext[i] = static_cast<double *>(dev_ptrs[i]);
+        else s->ext[i] = static_cast<float *>(dev_ptrs[i]);
+        s->has_ext = s->has_ext || dev_ptrs[i] != nullptr;
     }
     return NBODY_OK;
 }
@@ -503,6 +697,7 @@ int nbody_create(const nbody_params *params, nbody_t **out)
     s->cap = p.num_points;
     s->group = p.traversal_group_size;
     s->key_bytes = p.morton_bits == 10 ? 4 : 8;
+    s->fp64 = (p.flags & NBODY_FLAG_FP64) != 0;
     int dev = p.device_id;
     if (dev < 0 && hipGetDevice(&dev) != hipSuccess) { delete s; return NBODY_ERR_HIP; }
     s->device = dev;
@@ -543,7 +738,15 @@ int nbody_sample_ic(int kind, int n, uint64_t seed, float domain_size, float gra
                     float *m)
 {
     if (n < 1 || !x || !y || !z || !m) return NBODY_ERR_INVALID;
-    return sample_ic(kind, n, seed, domain_size, gravity, p0, p1, x, y, z, vx, vy, vz, m);
+    return sample_ic<float>(kind, n, seed, domain_size, gravity, p0, p1, x, y, z, vx, vy, vz, m);
+}
+
+int nbody_sample_ic_f64(int kind, int n, uint64_t seed, float domain_size, float gravity, float p0,
+                        float p1, double *x, double *y, double *z, double *vx, double *vy,
+                        double *vz, double *m)
+{
+    if (n < 1 || !x || !y || !z || !m) return NBODY_ERR_INVALID;
+    return sample_ic<double>(kind, n, seed, domain_size, gravity, p0, p1, x, y, z, vx, vy, vz, m);
 }
 
 #define NB_ENTER(h)                                  \
@@ -566,7 +769,15 @@ int nbody_set_state(nbody_t *h, const float *x, const float *y, const float *z, 
 {
     NB_ENTER(h);
     if (!x || !y || !z || !m) return fail(s, NBODY_ERR_INVALID, "set_state: x, y, z, m required");
-    return upload_state(s, x, y, z, vx, vy, vz, m);
+    return upload_state<float>(s, x, y, z, vx, vy, vz, m);
+}
+
+int nbody_set_state_f64(nbody_t *h, const double *x, const double *y, const double *z,
+                        const double *vx, const double *vy, const double *vz, const double *m)
+{
+    NB_ENTER(h);
+    if (!x || !y || !z || !m) return fail(s, NBODY_ERR_INVALID, "set_state: x, y, z, m required");
+    return upload_state<double>(s, x, y, z, vx, vy, vz, m);
 }
 
 int nbody_update(nbody_t *h)
@@ -588,18 +799,24 @@ int nbody_update(nbody_t *h)
     const bool sharded = s->trav_g1 >= 0;
     const bool fuse = !sharded && !(s->p.flags & NBODY_FLAG_NO_FUSED_VEL);
     NB_HIP(s, mark(EV_BEGIN));
-    NB_HIP(s, launch_integrate_morton(s));
+    NB_HIP(s, s->fp64 ? launch64_integrate_morton(s) : launch_integrate_morton(s));
     NB_HIP(s, mark(EV_INTEGRATE));
     int rc = build_after_encode(s, false);
     if (rc) return rc;
     NB_HIP(s, mark(EV_SORT));
     NB_HIP(s, launch_build(s));
     NB_HIP(s, mark(EV_BUILD));
-    NB_HIP(s, launch_com(s));
+    NB_HIP(s, s->fp64 ? launch64_com(s) : launch_com(s));
     NB_HIP(s, mark(EV_COM));
-    NB_HIP(s, launch_export_view(s));
-    NB_HIP(s, launch_traverse(s, fuse));
-    if (!fuse && !sharded) NB_HIP(s, launch_vel_kick(s));
+    if (s->fp64) {   // a double handle is never sharded (nbody_set_traversal_range refuses it)
+        NB_HIP(s, launch64_export_view(s));
+        NB_HIP(s, launch64_traverse(s, false));
+        NB_HIP(s, launch64_vel_kick(s));
+    } else {
+        NB_HIP(s, launch_export_view(s));
+        NB_HIP(s, launch_traverse(s, fuse));
+        if (!fuse && !sharded) NB_HIP(s, launch_vel_kick(s));
+    }
     NB_HIP(s, mark(EV_TRAVERSE));
     if (timing) {
         NB_HIP(s, launch_count_interactions(s, (unsigned long long *) (s->inter_dev + slot)));
@@ -608,13 +825,14 @@ int nbody_update(nbody_t *h)
         s->ev_pending++;
     }
     if (sharded) s->pending_vel = true;
-    if (s->p.num_steps_validator > 0 && !sharded) return validator_step(s);
+    if (s->p.num_steps_validator > 0 && !sharded) return s->fp64 ? validator_step64(s) : validator_step(s);
     return NBODY_OK;
 }
 
 int nbody_finish_step(nbody_t *h)
 {
     NB_ENTER(h);
+    NB_FLOAT_ONLY(s, "finish_step");
     if (!s->pending_vel) return fail(s, NBODY_ERR_STATE, "no sharded step pending");
     NB_HIP(s, launch_vel_kick(s));
     s->pending_vel = false;
@@ -624,6 +842,7 @@ int nbody_finish_step(nbody_t *h)
 int nbody_set_traversal_range(nbody_t *h, int32_t g0, int32_t g1)
 {
     NB_ENTER(h);
+    NB_FLOAT_ONLY(s, "set_traversal_range");
     const int ngroups = (s->n + s->group - 1) / s->group;
     if (g1 >= 0 && (g0 < 0 || g0 > g1 || g1 > ngroups))
         return fail(s, NBODY_ERR_INVALID, "traversal range outside [0, ngroups]");
@@ -672,17 +891,16 @@ int nbody_get_state(nbody_t *h, float *x, float *y, float *z, float *vx, float *
                     float *m, float *ax, float *ay, float *az, uint32_t *id)
 {
     NB_ENTER(h);
-    const size_t b = (size_t) s->n * 4;
-    const int c = s->cur;
-    auto D2H = [&](void *dst, const void *src) -> hipError_t {
-        return dst ? hipMemcpyAsync(dst, src, b, hipMemcpyDeviceToHost, s->stream) : hipSuccess;
-    };
-    NB_HIP(s, D2H(x, s->x[c])); NB_HIP(s, D2H(y, s->y[c])); NB_HIP(s, D2H(z, s->z[c]));
-    NB_HIP(s, D2H(vx, s->vx[c])); NB_HIP(s, D2H(vy, s->vy[c])); NB_HIP(s, D2H(vz, s->vz[c]));
-    NB_HIP(s, D2H(m, s->m[c]));
-    NB_HIP(s, D2H(ax, s->ax)); NB_HIP(s, D2H(ay, s->ay)); NB_HIP(s, D2H(az, s->az));
-    NB_HIP(s, D2H(id, s->id[c]));
-    return fetch_counts(s);
+    int rc = get_state<float>(s, x, y, z, vx, vy, vz, m, ax, ay, az, id);
+    return rc ? rc : fetch_counts(s);
+}
+
+int nbody_get_state_f64(nbody_t *h, double *x, double *y, double *z, double *vx, double *vy,
+                        double *vz, double *m, double *ax, double *ay, double *az, uint32_t *id)
+{
+    NB_ENTER(h);
+    int rc = get_state<double>(s, x, y, z, vx, vy, vz, m, ax, ay, az, id);
+    return rc ? rc : fetch_counts(s);
 }
 
 int nbody_get_device_ptrs(nbody_t *h, nbody_dev_view *out)
@@ -690,14 +908,35 @@ int nbody_get_device_ptrs(nbody_t *h, nbody_dev_view *out)
     NB_ENTER(h);
     if (!out) return fail(s, NBODY_ERR_INVALID, "null output");
     const int c = s->cur;
+    std::memset(out, 0, sizeof *out);
     out->n = s->n;
+    out->id = s->id[c];
+    out->stream = (void *) s->stream;
+    if (s->fp64) return NBODY_OK;   // no float arrays: nbody_get_device_ptrs_f64 has the doubles
     out->x = s->x[c]; out->y = s->y[c]; out->z = s->z[c];
     out->vx = s->vx[c]; out->vy = s->vy[c]; out->vz = s->vz[c];
     out->ax = s->ax; out->ay = s->ay; out->az = s->az;
     out->m = s->m[c];
     out->posm = reinterpret_cast<const float *>(s->posm);
+    return NBODY_OK;
+}
+
+int nbody_get_device_ptrs_f64(nbody_t *h, nbody_dev_view_f64 *out)
+{
+    NB_ENTER(h);
+    if (!out) return fail(s, NBODY_ERR_INVALID, "null output");
+    const int c = s->cur;
+    std::memset(out, 0, sizeof *out);
+    out->n = s->n;
     out->id = s->id[c];
     out->stream = (void *) s->stream;
+    if (!s->fp64) return NBODY_OK;
+    const State64 &d = s->d;
+    out->x = d.x[c]; out->y = d.y[c]; out->z = d.z[c];
+    out->vx = d.vx[c]; out->vy = d.vy[c]; out->vz = d.vz[c];
+    out->ax = d.ax; out->ay = d.ay; out->az = d.az;
+    out->m = d.m[c];
+    out->posm = reinterpret_cast<const double *>(d.posm);
     return NBODY_OK;
 }
 
@@ -737,18 +976,20 @@ int nbody_get_octree(nbody_t *h, nbody_octree_view *v)
     NB_HIP(s, D2H(v->points_end, s->o_pe, no * 4));
     NB_HIP(s, D2H(v->parent, s->o_parent, no * 4));
     if (v->comx || v->comy || v->comz || v->mass) {
-        std::vector<Float4> a(no);
-        NB_HIP(s, hipMemcpy(a.data(), s->nodeA, no * sizeof(Float4), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < no; ++i) {
-            if (v->comx) v->comx[i] = a[i].x;
-            if (v->comy) v->comy[i] = a[i].y;
-            if (v->comz) v->comz[i] = a[i].z;
-            if (v->mass) v->mass[i] = a[i].w;
-        }
+        int rc2 = get_com<float>(s, no, v->comx, v->comy, v->comz, v->mass);
+        if (rc2) return rc2;
     }
     const size_t ngroups = (n + s->group - 1) / s->group;
     NB_HIP(s, D2H(v->list_len, s->list_len, ngroups * 4));
     return NBODY_OK;
+}
+
+int nbody_get_octree_com_f64(nbody_t *h, double *comx, double *comy, double *comz, double *mass)
+{
+    NB_ENTER(h);
+    int rc = fetch_counts(s);
+    if (rc) return rc;
+    return get_com<double>(s, (size_t) s->counts_host->n_oct, comx, comy, comz, mass);
 }
 
 int nbody_get_timings(nbody_t *h, nbody_timings *out)
@@ -812,6 +1053,17 @@ int nbody_direct_sum(nbody_t *h, float *ax, float *ay, float *az)
     NB_ENTER(h);
     if (!s->spawned) return fail(s, NBODY_ERR_STATE, "direct sum before spawn/set_state");
     const size_t n = (size_t) s->n;
+    if (s->fp64) {   // computed in double, narrowed
+        std::vector<double> t(3 * n);
+        int rc = nbody_direct_sum_f64(h, &t[0], &t[n], &t[2 * n]);
+        if (rc) return rc;
+        for (size_t i = 0; i < n; ++i) {
+            if (ax) ax[i] = (float) t[i];
+            if (ay) ay[i] = (float) t[n + i];
+            if (az) az[i] = (float) t[2 * n + i];
+        }
+        return NBODY_OK;
+    }
     float *d = nullptr;
     NB_HIP(s, hipMalloc((void **) &d, 3 * n * 4));
     hipError_t e = launch_direct(s->posm, s->n, s->posm, s->n,
@@ -826,11 +1078,49 @@ int nbody_direct_sum(nbody_t *h, float *ax, float *ay, float *az)
     return NBODY_OK;
 }
 
+// The direct sum evaluated in double: on a double-precision handle over its own state, on a
+// float handle over its float positions and masses widened (the accuracy reference for the
+// float tree forces at sizes a host loop cannot reach).
+int nbody_direct_sum_f64(nbody_t *h, double *ax, double *ay, double *az)
+{
+    NB_ENTER(h);
+    if (!s->spawned) return fail(s, NBODY_ERR_STATE, "direct sum before spawn/set_state");
+    const size_t n = (size_t) s->n;
+    double *d = nullptr;
+    Double4 *wide = nullptr;
+    NB_HIP(s, hipMalloc((void **) &d, 3 * n * 8));
+    hipError_t e = hipSuccess;
+    const Double4 *src = s->d.posm;
+    if (!s->fp64) {
+        std::vector<Float4> p4(n);
+        std::vector<Double4> p8(n);
+        e = hipMemcpyAsync(p4.data(), s->posm, n * sizeof(Float4), hipMemcpyDeviceToHost, s->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+        for (size_t i = 0; i < n; ++i) p8[i] = Double4{p4[i].x, p4[i].y, p4[i].z, p4[i].w};
+        if (e == hipSuccess) e = hipMalloc((void **) &wide, n * sizeof(Double4));
+        if (e == hipSuccess) e = hipMemcpy(wide, p8.data(), n * sizeof(Double4), hipMemcpyHostToDevice);
+        src = wide;
+    }
+    const double eps = (double) s->p.softening_factor;
+    if (e == hipSuccess)
+        e = launch64_direct(src, s->n, src, s->n, eps * eps, (double) s->p.gravity, d, d + n, d + 2 * n,
+                            nullptr, 0, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    if (e == hipSuccess && ax) e = hipMemcpy(ax, d, n * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && ay) e = hipMemcpy(ay, d + n, n * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && az) e = hipMemcpy(az, d + 2 * n, n * 8, hipMemcpyDeviceToHost);
+    (void) hipFree(d);
+    if (wide) (void) hipFree(wide);
+    NB_HIP(s, e);
+    return NBODY_OK;
+}
+
 // ---- multi-GPU locally-essential-tree exchange (no counterpart in the single-GPU reference) ----
 
 int nbody_get_bbox(nbody_t *h, float *lo_hi)
 {
     NB_ENTER(h);
+    NB_FLOAT_ONLY(s, "nbody_get_bbox");
     if (!lo_hi) return fail(s, NBODY_ERR_INVALID, "null output");
     if (!s->spawned || s->n < 1) return fail(s, NBODY_ERR_STATE, "bbox of an empty handle");
     uint32_t *box = s->let_counts + LET_MAX_BOXES;
@@ -846,6 +1136,7 @@ int nbody_let_export(nbody_t *h, const float *boxes, int32_t nboxes, float *out_
                      int32_t capacity, int32_t *counts)
 {
     NB_ENTER(h);
+    NB_FLOAT_ONLY(s, "nbody_let_export");
     if (!boxes || !out_dev || !counts || nboxes < 0 || nboxes > LET_MAX_BOXES || capacity < 0)
         return fail(s, NBODY_ERR_INVALID, "let_export: bad arguments");
     if (!s->spawned || s->n < 1) return fail(s, NBODY_ERR_STATE, "let_export before spawn/set_state");
@@ -865,6 +1156,7 @@ int nbody_let_export(nbody_t *h, const float *boxes, int32_t nboxes, float *out_
 int nbody_set_sources_dev(nbody_t *h, const float *posm_dev, int32_t count)
 {
     NB_ENTER(h);
+    NB_FLOAT_ONLY(s, "nbody_set_sources_dev");
     if (count < 0 || count > s->cap || (count > 0 && !posm_dev))
         return fail(s, NBODY_ERR_INVALID, "set_sources: count outside [0, num_points]");
     if (s->p.num_steps_validator > 0)
@@ -885,8 +1177,10 @@ int nbody_set_sources_dev(nbody_t *h, const float *posm_dev, int32_t count)
 int nbody_traverse_from(nbody_t *h, nbody_t *sources, int32_t accumulate)
 {
     NB_ENTER(h);
+    NB_FLOAT_ONLY(s, "nbody_traverse_from");
     if (!sources) return fail(s, NBODY_ERR_INVALID, "null sources");
     Sim *src = reinterpret_cast<Sim *>(sources);
+    if (src->fp64) return fail(s, NBODY_ERR_STATE, "traverse_from: sources are a double-precision handle");
     if (!s->spawned) return fail(s, NBODY_ERR_STATE, "traverse_from before spawn/set_state");
     if (src->device != s->device || src->key_bytes != s->key_bytes)
         return fail(s, NBODY_ERR_INVALID, "traverse_from: handles differ in device or key width");
@@ -929,6 +1223,29 @@ int nbody_tree_energy(nbody_t *h, double *kinetic, double *potential)
     NB_ENTER(h);
     if (!s->spawned) return fail(s, NBODY_ERR_STATE, "energy before spawn/set_state");
     if (s->pending_vel) return fail(s, NBODY_ERR_STATE, "nbody_finish_step not called");
+    if (s->fp64) {
+        State64 &d = s->d;
+        const size_t n = (size_t) s->n, b = n * 8;
+        if (!d.pot) NB_HIP(s, dalloc(&d.pot, (size_t) s->cap));
+        NB_HIP(s, launch64_traverse(s, true));
+        const int c = s->cur;
+        std::vector<double> m(n), vx(n), vy(n), vz(n), pot(n);
+        NB_HIP(s, hipMemcpyAsync(m.data(), d.m[c], b, hipMemcpyDeviceToHost, s->stream));
+        NB_HIP(s, hipMemcpyAsync(vx.data(), d.vx[c], b, hipMemcpyDeviceToHost, s->stream));
+        NB_HIP(s, hipMemcpyAsync(vy.data(), d.vy[c], b, hipMemcpyDeviceToHost, s->stream));
+        NB_HIP(s, hipMemcpyAsync(vz.data(), d.vz[c], b, hipMemcpyDeviceToHost, s->stream));
+        NB_HIP(s, hipMemcpyAsync(pot.data(), d.pot, b, hipMemcpyDeviceToHost, s->stream));
+        int rc = fetch_counts(s);
+        if (rc) return rc;
+        double ke = 0, pe = 0;
+        for (size_t i = 0; i < n; ++i) {
+            ke += 0.5 * m[i] * (vx[i] * vx[i] + vy[i] * vy[i] + vz[i] * vz[i]);
+            pe -= 0.5 * (double) s->p.gravity * m[i] * pot[i];
+        }
+        if (kinetic) *kinetic = ke;
+        if (potential) *potential = pe;
+        return NBODY_OK;
+    }
     const size_t n = (size_t) s->n, b = n * 4;
     if (!s->pot) {
         NB_HIP(s, dalloc(&s->pot, (size_t) s->cap));
@@ -960,33 +1277,58 @@ namespace {
 struct SnapHeader {
     char magic[8];       // "NBSNAP1"
     int32_t n;
-    int32_t reserved;
+    int32_t real_bytes;  // 8: double payload, anything else: float payload
     float domain_size;
     float pad;
 };
 }  // namespace
+
+extern "C++" {
+namespace {
+template <typename R>
+int save_snapshot(Sim *s, const char *path)
+{
+    const size_t n = (size_t) s->n;
+    std::vector<R> buf(10 * n);
+    std::vector<uint32_t> id(n);
+    int rc = get_state<R>(s, &buf[0], &buf[n], &buf[2 * n], &buf[3 * n], &buf[4 * n], &buf[5 * n],
+                          &buf[6 * n], &buf[7 * n], &buf[8 * n], &buf[9 * n], id.data());
+    if (!rc) rc = fetch_counts(s);
+    if (rc) return rc;
+    SnapHeader hd{};
+    std::memcpy(hd.magic, "NBSNAP1", 8);
+    hd.n = s->n;
+    hd.real_bytes = (int32_t) sizeof(R);
+    hd.domain_size = s->p.domain_size;
+    std::ofstream out(path, std::ios::binary);
+    if (!out) return fail(s, NBODY_ERR_IO, std::string("cannot open ") + path);
+    out.write(reinterpret_cast<const char *>(&hd), sizeof hd);
+    out.write(reinterpret_cast<const char *>(buf.data()), (std::streamsize) (buf.size() * sizeof(R)));
+    out.write(reinterpret_cast<const char *>(id.data()), (std::streamsize) (n * 4));
+    return out ? NBODY_OK : fail(s, NBODY_ERR_IO, "write failed");
+}
+
+template <typename R>
+int load_snapshot(Sim *s, std::ifstream &in, int count)
+{
+    const size_t n = (size_t) count;
+    std::vector<R> buf(10 * n);
+    std::vector<uint32_t> id(n);
+    in.read(reinterpret_cast<char *>(buf.data()), (std::streamsize) (buf.size() * sizeof(R)));
+    in.read(reinterpret_cast<char *>(id.data()), (std::streamsize) (n * 4));
+    if (!in) return fail(s, NBODY_ERR_IO, "truncated snapshot");
+    return set_particles<R>(s, count, &buf[0], &buf[n], &buf[2 * n], &buf[3 * n], &buf[4 * n], &buf[5 * n],
+                            &buf[6 * n], &buf[7 * n], &buf[8 * n], &buf[9 * n], id.data());
+}
+}  // namespace
+}  // extern "C++"
 
 int nbody_save_snapshot(nbody_t *h, const char *path)
 {
     NB_ENTER(h);
     if (!path) return fail(s, NBODY_ERR_INVALID, "null path");
     if (!s->spawned) return fail(s, NBODY_ERR_STATE, "snapshot before spawn/set_state");
-    const size_t n = (size_t) s->n;
-    std::vector<float> buf(10 * n);
-    std::vector<uint32_t> id(n);
-    int rc = nbody_get_state(h, &buf[0], &buf[n], &buf[2 * n], &buf[3 * n], &buf[4 * n], &buf[5 * n],
-                             &buf[6 * n], &buf[7 * n], &buf[8 * n], &buf[9 * n], id.data());
-    if (rc) return rc;
-    SnapHeader hd{};
-    std::memcpy(hd.magic, "NBSNAP1", 8);
-    hd.n = s->n;
-    hd.domain_size = s->p.domain_size;
-    std::ofstream out(path, std::ios::binary);
-    if (!out) return fail(s, NBODY_ERR_IO, std::string("cannot open ") + path);
-    out.write(reinterpret_cast<const char *>(&hd), sizeof hd);
-    out.write(reinterpret_cast<const char *>(buf.data()), (std::streamsize) (buf.size() * 4));
-    out.write(reinterpret_cast<const char *>(id.data()), (std::streamsize) (n * 4));
-    return out ? NBODY_OK : fail(s, NBODY_ERR_IO, "write failed");
+    return s->fp64 ? save_snapshot<double>(s, path) : save_snapshot<float>(s, path);
 }
 
 int nbody_load_snapshot(nbody_t *h, const char *path)
@@ -999,14 +1341,9 @@ int nbody_load_snapshot(nbody_t *h, const char *path)
     in.read(reinterpret_cast<char *>(&hd), sizeof hd);
     if (!in || std::memcmp(hd.magic, "NBSNAP1", 8) != 0) return fail(s, NBODY_ERR_IO, "not a snapshot file");
     if (hd.n != s->cap) return fail(s, NBODY_ERR_INVALID, "snapshot particle count differs from num_points");
-    const size_t n = (size_t) hd.n;
-    std::vector<float> buf(10 * n);
-    std::vector<uint32_t> id(n);
-    in.read(reinterpret_cast<char *>(buf.data()), (std::streamsize) (buf.size() * 4));
-    in.read(reinterpret_cast<char *>(id.data()), (std::streamsize) (n * 4));
-    if (!in) return fail(s, NBODY_ERR_IO, "truncated snapshot");
-    return set_particles(s, hd.n, &buf[0], &buf[n], &buf[2 * n], &buf[3 * n], &buf[4 * n], &buf[5 * n],
-                         &buf[6 * n], &buf[7 * n], &buf[8 * n], &buf[9 * n], id.data());
+    // a payload of the other precision is converted; a restart is bit-identical only when
+    // file and handle agree
+    return hd.real_bytes == 8 ? load_snapshot<double>(s, in, hd.n) : load_snapshot<float>(s, in, hd.n);
 }
 
 int nbody_set_particles(nbody_t *h, int32_t count, const float *x, const float *y, const float *z,
@@ -1018,7 +1355,7 @@ int nbody_set_particles(nbody_t *h, int32_t count, const float *x, const float *
     if (!x || !y || !z || !m) return fail(s, NBODY_ERR_INVALID, "set_particles: x, y, z, m required");
     if (s->p.num_steps_validator > 0 && count != s->cap)
         return fail(s, NBODY_ERR_STATE, "set_particles: a handle with a validator keeps num_points particles");
-    return set_particles(s, count, x, y, z, vx, vy, vz, m, ax, ay, az, id);
+    return set_particles<float>(s, count, x, y, z, vx, vy, vz, m, ax, ay, az, id);
 }
 
 int nbody_write_validation_history(nbody_t *h, const char *csv_path)

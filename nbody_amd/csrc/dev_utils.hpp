@@ -23,6 +23,30 @@ __device__ __forceinline__ int mbcnt(unsigned long long mask)
                                            __builtin_amdgcn_mbcnt_lo((unsigned) mask, 0u));
 }
 
+// Morton bit spreading (reference: expand_bits, src/cuda/points.cu:3-12).
+// 10-bit -> 30-bit spread (bit k -> bit 3k).
+__device__ __forceinline__ uint32_t spread3_10(uint32_t u)
+{
+    u &= 0x3ffu;
+    u = (u | (u << 16)) & 0x030000FFu;
+    u = (u | (u << 8)) & 0x0300F00Fu;
+    u = (u | (u << 4)) & 0x030C30C3u;
+    u = (u | (u << 2)) & 0x09249249u;
+    return u;
+}
+
+// 21-bit -> 63-bit spread (bit k -> bit 3k).
+__device__ __forceinline__ uint64_t spread3_21(uint64_t u)
+{
+    u &= 0x1fffffull;
+    u = (u | (u << 32)) & 0x001f00000000ffffull;
+    u = (u | (u << 16)) & 0x001f0000ff0000ffull;
+    u = (u | (u << 8)) & 0x100f00f00f00f00full;
+    u = (u | (u << 4)) & 0x10c30c30c30c30c3ull;
+    u = (u | (u << 2)) & 0x1249249249249249ull;
+    return u;
+}
+
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 {
 #pragma unroll

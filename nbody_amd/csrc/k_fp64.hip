@@ -1,0 +1,601 @@
+// k_fp64.hip -- the floating-point stages of a double-precision handle.
+//
+// The reference instantiates every class for float and for double
+// (src/cuda/simulation.cu:255-256, points.cu:228, octree.cu:367, barnes_hut.cu:677,
+// validator.cu:381, physics_common.cuh:103) and chooses one at build time; its
+// "all-pairs (double)" energy curves come from the double build.  Here precision is a
+// property of the handle (NBODY_FLAG_FP64).  Keys, the sort and every tree array are
+// integer work and are shared with the float path; this file holds what touches
+// coordinates: kick-drift + Morton encode, the particle permute, centres of mass, the
+// group traversal, the velocity kick and the direct sum, all in double.
+//
+// MI355X executes v_fma_f64 at half the FP32 rate and has no packed double ops, so these
+// kernels are plain one-body-per-lane code: sources staged through LDS and broadcast.
+#include <algorithm>
+
+#include "dev_utils.hpp"
+#include "nbody_internal.hpp"
+
+namespace nb {
+
+namespace {
+
+// q = (uint)(p / domain * (2^B - 1)) with the division and the product in double
+// (src/cuda/points.cu:28-30 with T = double; domain_size stays a float parameter).
+template <typename KeyT>
+__device__ __forceinline__ KeyT morton_code_d(double px, double py, double pz, double domain)
+{
+    if constexpr (sizeof(KeyT) == 4) {
+        const double s = 1023.0;
+        const uint32_t qx = (uint32_t) (uint64_t) ((px / domain) * s);
+        const uint32_t qy = (uint32_t) (uint64_t) ((py / domain) * s);
+        const uint32_t qz = (uint32_t) (uint64_t) ((pz / domain) * s);
+        return spread3_10(qx) * 4u + spread3_10(qy) * 2u + spread3_10(qz);
+    } else {
+        const double s = 2097151.0;
+        const uint64_t qx = (uint64_t) ((px / domain) * s);
+        const uint64_t qy = (uint64_t) ((py / domain) * s);
+        const uint64_t qz = (uint64_t) ((pz / domain) * s);
+        return spread3_21(qx) * 4ull + spread3_21(qy) * 2ull + spread3_21(qz);
+    }
+}
+
+__device__ __forceinline__ void reflect_d(double &p, double &v, double domain)
+{
+    if (p < 0.0 || p > domain) {
+        v *= -1.0;
+        p = fmax(0.0, fmin(domain, p));
+    }
+}
+
+// leapfrog_integrate_pos + impose_boundary_conditions (src/cuda/physics_common.cu:69-147)
+// followed by the Morton code of the new position.
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k64_integrate_morton(
+    int n, double dt, double domain, double *__restrict__ x, double *__restrict__ y,
+    double *__restrict__ z, const double *__restrict__ vx, const double *__restrict__ vy,
+    const double *__restrict__ vz, const double *__restrict__ ax, const double *__restrict__ ay,
+    const double *__restrict__ az, double *__restrict__ vhx, double *__restrict__ vhy,
+    double *__restrict__ vhz, KeyT *__restrict__ codes)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double hx = fma(0.5 * ax[i], dt, vx[i]);
+    double hy = fma(0.5 * ay[i], dt, vy[i]);
+    double hz = fma(0.5 * az[i], dt, vz[i]);
+    double px = fma(hx, dt, x[i]);
+    double py = fma(hy, dt, y[i]);
+    double pz = fma(hz, dt, z[i]);
+    reflect_d(px, hx, domain);
+    reflect_d(py, hy, domain);
+    reflect_d(pz, hz, domain);
+    x[i] = px; y[i] = py; z[i] = pz;
+    vhx[i] = hx; vhy[i] = hy; vhz[i] = hz;
+    codes[i] = morton_code_d<KeyT>(px, py, pz, domain);
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k64_morton(int n, double domain, const double *__restrict__ x,
+                                                  const double *__restrict__ y,
+                                                  const double *__restrict__ z,
+                                                  KeyT *__restrict__ codes)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    codes[i] = morton_code_d<KeyT>(x[i], y[i], z[i], domain);
+}
+
+struct Perm64 {
+    const double *xi, *yi, *zi, *mi, *hxi, *hyi, *hzi, *vxi, *vyi, *vzi;
+    double *xo, *yo, *zo, *mo, *hxo, *hyo, *hzo, *vxo, *vyo, *vzo;
+    const uint32_t *idi;
+    uint32_t *ido;
+    Double4 *posm;
+};
+
+// Points::sort_by_codes / BarnesHut::sort_bodies gathers (src/cuda/points.cu:86-113,
+// src/cuda/barnes_hut.cu:577-587) in one pass; ALL = velocities too (after a spawn).
+template <bool ALL>
+__global__ __launch_bounds__(256) void k64_permute(int n, const uint32_t *__restrict__ perm, Perm64 a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = perm[i];
+    const double px = a.xi[s], py = a.yi[s], pz = a.zi[s], pm = a.mi[s];
+    a.xo[i] = px; a.yo[i] = py; a.zo[i] = pz; a.mo[i] = pm;
+    a.hxo[i] = a.hxi[s]; a.hyo[i] = a.hyi[s]; a.hzo[i] = a.hzi[s];
+    a.ido[i] = a.idi[s];
+    a.posm[i] = Double4{px, py, pz, pm};
+    if (ALL) {
+        a.vxo[i] = a.vxi[s]; a.vyo[i] = a.vyi[s]; a.vzo[i] = a.vzi[s];
+    }
+}
+
+// leapfrog_integrate_vel (src/cuda/physics_common.cu:120-147): v = (v_half + 0.5 a dt)(1 - damp)
+__global__ __launch_bounds__(256) void k64_vel_kick(int n, double dt, double keep,
+                                                    const double *__restrict__ vhx,
+                                                    const double *__restrict__ vhy,
+                                                    const double *__restrict__ vhz,
+                                                    const double *__restrict__ ax,
+                                                    const double *__restrict__ ay,
+                                                    const double *__restrict__ az,
+                                                    double *__restrict__ vx, double *__restrict__ vy,
+                                                    double *__restrict__ vz)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    vx[i] = fma(0.5 * ax[i], dt, vhx[i]) * keep;
+    vy[i] = fma(0.5 * ay[i], dt, vhy[i]) * keep;
+    vz[i] = fma(0.5 * az[i], dt, vhz[i]) * keep;
+}
+
+// Kick-drift of the validator's all-pairs twin (positions in the packed record).
+__global__ __launch_bounds__(256) void k64_twin_kick_drift(
+    int n, double dt, double domain, Double4 *__restrict__ posm, const double *__restrict__ vx,
+    const double *__restrict__ vy, const double *__restrict__ vz, const double *__restrict__ ax,
+    const double *__restrict__ ay, const double *__restrict__ az, double *__restrict__ vhx,
+    double *__restrict__ vhy, double *__restrict__ vhz)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Double4 p = posm[i];
+    double hx = fma(0.5 * ax[i], dt, vx[i]);
+    double hy = fma(0.5 * ay[i], dt, vy[i]);
+    double hz = fma(0.5 * az[i], dt, vz[i]);
+    p.x = fma(hx, dt, p.x);
+    p.y = fma(hy, dt, p.y);
+    p.z = fma(hz, dt, p.z);
+    reflect_d(p.x, hx, domain);
+    reflect_d(p.y, hy, domain);
+    reflect_d(p.z, hz, domain);
+    posm[i] = p;
+    vhx[i] = hx; vhy[i] = hy; vhz[i] = hz;
+}
+
+// Centre of mass: the float kernel's single-launch climb (k_tree.hip, k_com) in double.
+// A thread sums its leaf's particles in index order and climbs; the last child to arrive
+// at a parent sums the parent's children in index order, so the summation order is fixed
+// and the host checker reproduces the result bit for bit
+// (src/cuda/octree.cu:109-217,292-346 is the level-by-level original).
+__device__ __forceinline__ void st_wt(double *p, double v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_wt(const double *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void k64_com(const Counts *counts,
+                                               const int32_t *__restrict__ o_num_children,
+                                               const int32_t *__restrict__ o_first_child,
+                                               const int32_t *__restrict__ o_pb,
+                                               const int32_t *__restrict__ o_pe,
+                                               const int32_t *__restrict__ o_parent,
+                                               const Double4 *__restrict__ posm, Double4 *wsum,
+                                               Double4 *__restrict__ nodeA, uint32_t *counter)
+{
+    const int n_oct = counts->n_oct;
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < n_oct; o += gridDim.x * 256) {
+        if (o_num_children[o] != 0) continue;
+        double sx = 0.0, sy = 0.0, sz = 0.0, sm = 0.0;
+        const int pb = o_pb[o], pe = o_pe[o];
+        for (int p = pb; p <= pe; ++p) {
+            const Double4 q = posm[p];
+            sx = fma(q.w, q.x, sx);
+            sy = fma(q.w, q.y, sy);
+            sz = fma(q.w, q.z, sz);
+            sm += q.w;
+        }
+        int cur = o;
+        int guard = 0;
+        while (true) {
+            double *ws = reinterpret_cast<double *>(&wsum[cur]);
+            st_wt(ws + 0, sx); st_wt(ws + 1, sy); st_wt(ws + 2, sz); st_wt(ws + 3, sm);
+            nodeA[cur] = Double4{sx / sm, sy / sm, sz / sm, sm};
+            const int parent = o_parent[cur];
+            if (parent < 0 || ++guard > 64) break;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint32_t arrived = __hip_atomic_fetch_add(&counter[parent], 1u, __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT);
+            const int nc = o_num_children[parent];
+            if ((int) arrived != nc - 1) break;
+            __hip_atomic_store(&counter[parent], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int fc = o_first_child[parent];
+            sx = sy = sz = sm = 0.0;
+            for (int c = fc; c < fc + nc; ++c) {
+                const double *cs = reinterpret_cast<const double *>(&wsum[c]);
+                sx += ld_wt(cs + 0);
+                sy += ld_wt(cs + 1);
+                sz += ld_wt(cs + 2);
+                sm += ld_wt(cs + 3);
+            }
+            cur = parent;
+        }
+    }
+}
+
+// 1/sqrt(t), t > 0: v_rsq_f64 seeds two Newton steps y <- y + (y/2)(1 - t y^2), which
+// square the seed's relative error twice.
+__device__ __forceinline__ double rsq64(double t)
+{
+    double y = __builtin_amdgcn_rsq(t);
+    double e = fma(-t * y, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    e = fma(-t * y, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    return y;
+}
+
+// ---------------------------------------------------------------------------
+// Group traversal (src/cuda/barnes_hut.cu:199-537) in double.  One wave64 per group of G
+// Morton-consecutive bodies, lane = body.  The wave keeps a stack of node ids in LDS and
+// pops up to 64 per round, one per lane:
+//   * a node without children contributes its particles (always direct, self included);
+//   * otherwise the lane computes d2min = min over the group's bodies of |x_b - com|^2
+//     (initial value 3 domain^2) and accepts (com, mass) iff size^2 / d2min < theta^2,
+//     else pushes the children.
+// The decisions use the operation sequence of the host checker, so each group's source
+// list is identical to it.  Accepted monopoles and leaf particles go through an LDS ring
+// that every lane reads back (broadcast) 64 sources at a time.
+// Stack discipline: a round pops only as many nodes as can push 8 children each without
+// passing capacity - reserve; when not even one fits the round pops one node and may use
+// the reserve, which makes those rounds depth-first: the entries above the mark are then
+// at most 7 siblings per level of a chain of strictly increasing depth, and the reserve
+// of 7 * 24 covers every level a 63-bit key has.
+// ---------------------------------------------------------------------------
+constexpr int T64_WAVES = 4;
+constexpr int T64_STACK = 1024;
+constexpr int T64_RESERVE = 7 * 24;
+constexpr int T64_RING = 128;
+
+struct alignas(16) T64Lds {
+    Double4 ring[T64_RING];
+    double bx[64], by[64], bz[64];
+    int stack[T64_STACK];
+    int lfirst[64];
+    int lscan[64];
+};
+
+template <int G, bool POT>
+__global__ __launch_bounds__(64 * T64_WAVES) void k64_traverse(
+    int n, int ngroups, const Double4 *__restrict__ posm, const Double4 *__restrict__ nodeA,
+    const NodeB *__restrict__ nodeB, double theta2, double eps2, double gravity, double dinit,
+    double *__restrict__ ax, double *__restrict__ ay, double *__restrict__ az,
+    double *__restrict__ pot, uint32_t *__restrict__ list_len, uint32_t *err)
+{
+    __shared__ T64Lds lds[T64_WAVES];
+    const int lane = (int) threadIdx.x & 63, w = (int) threadIdx.x >> 6;
+    const int g = (int) blockIdx.x * T64_WAVES + w;
+    if (g >= ngroups) return;   // whole wave; the kernel has no workgroup barrier
+    T64Lds &L = lds[w];
+    const int b0 = g * G;
+    const int nb = min(G, n - b0);
+    const bool active = lane < nb;
+    const Double4 me = posm[active ? b0 + lane : b0];
+    L.bx[lane] = me.x; L.by[lane] = me.y; L.bz[lane] = me.z;
+    if (lane == 0) L.stack[0] = 0;
+    int sp = 1;
+    __builtin_amdgcn_wave_barrier();
+
+    double fx = 0.0, fy = 0.0, fz = 0.0, ps = 0.0;
+    int head = 0, cnt = 0;   // ring entries [head, head + cnt) mod T64_RING
+    uint32_t total = 0;
+
+    auto force = [&](const Double4 s) {
+        const double dx = s.x - me.x, dy = s.y - me.y, dz = s.z - me.z;
+        const double t = fma(dz, dz, fma(dy, dy, fma(dx, dx, eps2)));
+        if (POT) {
+            ps = fma(s.w, rsq64(t), ps);
+        } else {
+            const double inv = s.w * rsq64(t * t * t);
+            fx = fma(dx, inv, fx);
+            fy = fma(dy, inv, fy);
+            fz = fma(dz, inv, fz);
+        }
+    };
+    auto flush = [&](int k) {   // every lane evaluates the ring's first k entries
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+        for (int j = 0; j < k; ++j) force(L.ring[(head + j) & (T64_RING - 1)]);
+        head = (head + k) & (T64_RING - 1);
+        cnt -= k;
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto append = [&](bool want, const Double4 v) {
+        const unsigned long long wm = __ballot(want);
+        if (wm == 0ull) return;
+        if (want) L.ring[(head + cnt + mbcnt(wm)) & (T64_RING - 1)] = v;
+        cnt += (int) __popcll(wm);
+        if (cnt >= 64) flush(64);
+    };
+
+    int rounds = 0;
+    while (sp > 0) {
+        if (++rounds > (1 << 22) || sp > T64_STACK - 8) {   // cannot happen: see the discipline above
+            if (lane == 0) atomicOr(err, DEV_ERR_STACK);
+            break;
+        }
+        const int fit = (T64_STACK - T64_RESERVE - sp) / 7;
+        const int p = fit >= 1 ? min(min(64, sp), fit) : 1;
+        const int node = lane < p ? L.stack[sp - p + lane] : -1;
+        sp -= p;
+        __builtin_amdgcn_wave_barrier();
+
+        bool is_leaf = false, accept = false, open = false;
+        NodeB B{0.f, 0, 0, 0u};
+        Double4 A{0.0, 0.0, 0.0, 0.0};
+        if (node >= 0) {
+            B = nodeB[node];
+            is_leaf = (B.meta & NODE_LEAF) != 0u;
+            if (!is_leaf) {
+                A = nodeA[node];
+                double dmin = dinit;
+                for (int j = 0; j < nb; ++j) {
+                    const double dx = L.bx[j] - A.x, dy = L.by[j] - A.y, dz = L.bz[j] - A.z;
+                    const double d = fma(dz, dz, fma(dy, dy, dx * dx));
+                    if (d <= dmin) dmin = d;
+                }
+                const double sz = (double) B.size;
+                accept = sz * sz / dmin < theta2;
+                open = !accept;
+            }
+        }
+        total += (uint32_t) __popcll(__ballot(accept));
+        append(accept, A);
+
+        {   // children of opened nodes back on the stack
+            const uint32_t nc = open ? (uint32_t) B.count : 0u;
+            const uint32_t incl = wave_incl_scan_u32(nc);
+            const int tot = (int) __shfl(incl, 63, 64);
+            const int at = sp + (int) (incl - nc);
+            for (uint32_t c = 0; c < nc; ++c) L.stack[at + (int) c] = B.first + (int) c;
+            sp += tot;
+        }
+        {   // particles of the popped leaves, 64 at a time in leaf order
+            const uint32_t lc = is_leaf ? (uint32_t) B.count : 0u;
+            const uint32_t incl = wave_incl_scan_u32(lc);
+            const int ltot = (int) __shfl(incl, 63, 64);
+            if (ltot > 0) {
+                L.lfirst[lane] = B.first;
+                L.lscan[lane] = (int) (incl - lc);
+                __builtin_amdgcn_wave_barrier();
+                for (int k0 = 0; k0 < ltot; k0 += 64) {
+                    const int k = k0 + lane;
+                    const bool want = k < ltot;
+                    int i = 0;   // the last lane whose first particle index is <= k owns particle k
+#pragma unroll
+                    for (int step = 32; step > 0; step >>= 1)
+                        if (L.lscan[i + step] <= k) i += step;
+                    const Double4 v = posm[want ? L.lfirst[i] + (k - L.lscan[i]) : 0];
+                    append(want, v);
+                }
+                total += (uint32_t) ltot;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (cnt > 0) flush(cnt);
+
+    if (active) {
+        const int b = b0 + lane;
+        if (POT) {
+            pot[b] = ps - me.w * rsq64(eps2);   // the body's own term, met exactly once
+        } else {
+            ax[b] = gravity * fx; ay[b] = gravity * fy; az[b] = gravity * fz;
+        }
+    }
+    if (lane == 0 && !POT) list_len[g] = total;
+}
+
+// ---------------------------------------------------------------------------
+// Direct sum (compute_ap_forces, src/cuda/validator.cu:134-174) in double: 256 targets per
+// workgroup, sources staged through LDS 256 at a time.  With `pot` the kernel also returns
+// pot_i = sum_j m_j / sqrt(d^2 + eps^2); self_pairs removes the j = i term again (targets
+// and sources are the same array), exact because both sides evaluate m_i * rsq(eps^2).
+// ---------------------------------------------------------------------------
+template <bool POT>
+__global__ __launch_bounds__(256) void k64_direct(const Double4 *__restrict__ targets, int nt,
+                                                  const Double4 *__restrict__ sources, int ns,
+                                                  double eps2, double gravity,
+                                                  double *__restrict__ ax, double *__restrict__ ay,
+                                                  double *__restrict__ az, double *__restrict__ pot,
+                                                  int self_pairs)
+{
+    __shared__ Double4 s_src[256];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const Double4 me = targets[i < nt ? i : 0];
+    double fx = 0.0, fy = 0.0, fz = 0.0, ps = 0.0;
+    for (int t0 = 0; t0 < ns; t0 += 256) {
+        const int c = min(256, ns - t0);
+        const int t = (int) threadIdx.x;
+        s_src[t] = t < c ? sources[t0 + t] : Double4{0.0, 0.0, 0.0, 0.0};   // massless pad
+        __syncthreads();
+#pragma unroll 4
+        for (int j = 0; j < c; ++j) {
+            const Double4 s = s_src[j];
+            const double dx = s.x - me.x, dy = s.y - me.y, dz = s.z - me.z;
+            const double tt = fma(dz, dz, fma(dy, dy, fma(dx, dx, eps2)));
+            double inv;
+            if (POT) {
+                const double r = rsq64(tt);
+                const double mr = s.w * r;
+                ps += mr;
+                inv = mr * r * r;
+            } else {
+                inv = s.w * rsq64(tt * tt * tt);
+            }
+            fx = fma(dx, inv, fx);
+            fy = fma(dy, inv, fy);
+            fz = fma(dz, inv, fz);
+        }
+        __syncthreads();
+    }
+    if (i < nt) {
+        ax[i] = gravity * fx; ay[i] = gravity * fy; az[i] = gravity * fz;
+        if (POT) pot[i] = self_pairs ? ps - me.w * rsq64(eps2) : ps;
+    }
+}
+
+// Viewer buffers of Simulation<double>(Params&, GLuint[7]) (src/cuda/simulation.cu:39-51,
+// 138-158): positions and the nodes' centres of mass and sizes, as doubles.
+__global__ __launch_bounds__(256) void k64_export_view(int n, const Counts *counts,
+                                                       const Double4 *__restrict__ posm,
+                                                       const Double4 *__restrict__ nodeA,
+                                                       const NodeB *__restrict__ nodeB, double *px,
+                                                       double *py, double *pz, double *cx,
+                                                       double *cy, double *cz, double *sz)
+{
+    const int n_oct = counts->n_oct;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < max(n, n_oct); i += gridDim.x * 256) {
+        if (i < n) {
+            const Double4 p = posm[i];
+            if (px) px[i] = p.x;
+            if (py) py[i] = p.y;
+            if (pz) pz[i] = p.z;
+        }
+        if (i < n_oct) {
+            const Double4 a = nodeA[i];
+            if (cx) cx[i] = a.x;
+            if (cy) cy[i] = a.y;
+            if (cz) cz[i] = a.z;
+            if (sz) sz[i] = (double) nodeB[i].size;
+        }
+    }
+}
+
+inline int nblk(int n, int t) { return (n + t - 1) / t; }
+
+}  // namespace
+
+hipError_t launch64_integrate_morton(Sim *s)
+{
+    State64 &d = s->d;
+    const int c = s->cur;
+    if (s->key_bytes == 4)
+        hipLaunchKernelGGL(k64_integrate_morton<uint32_t>, dim3(nblk(s->n, 256)), dim3(256), 0,
+                           s->stream, s->n, (double) s->p.dt, (double) s->p.domain_size, d.x[c],
+                           d.y[c], d.z[c], d.vx[c], d.vy[c], d.vz[c], d.ax, d.ay, d.az, d.vhx[c],
+                           d.vhy[c], d.vhz[c], (uint32_t *) s->keys[0]);
+    else
+        hipLaunchKernelGGL(k64_integrate_morton<uint64_t>, dim3(nblk(s->n, 256)), dim3(256), 0,
+                           s->stream, s->n, (double) s->p.dt, (double) s->p.domain_size, d.x[c],
+                           d.y[c], d.z[c], d.vx[c], d.vy[c], d.vz[c], d.ax, d.ay, d.az, d.vhx[c],
+                           d.vhy[c], d.vhz[c], (uint64_t *) s->keys[0]);
+    return hipGetLastError();
+}
+
+hipError_t launch64_morton_only(Sim *s)
+{
+    State64 &d = s->d;
+    const int c = s->cur;
+    if (s->key_bytes == 4)
+        hipLaunchKernelGGL(k64_morton<uint32_t>, dim3(nblk(s->n, 256)), dim3(256), 0, s->stream,
+                           s->n, (double) s->p.domain_size, d.x[c], d.y[c], d.z[c],
+                           (uint32_t *) s->keys[0]);
+    else
+        hipLaunchKernelGGL(k64_morton<uint64_t>, dim3(nblk(s->n, 256)), dim3(256), 0, s->stream,
+                           s->n, (double) s->p.domain_size, d.x[c], d.y[c], d.z[c],
+                           (uint64_t *) s->keys[0]);
+    return hipGetLastError();
+}
+
+hipError_t launch64_permute(Sim *s, bool all_fields)
+{
+    State64 &d = s->d;
+    const int c = s->cur, o = c ^ 1;
+    Perm64 a{d.x[c], d.y[c], d.z[c], d.m[c], d.vhx[c], d.vhy[c], d.vhz[c], d.vx[c], d.vy[c], d.vz[c],
+             d.x[o], d.y[o], d.z[o], d.m[o], d.vhx[o], d.vhy[o], d.vhz[o], d.vx[o], d.vy[o], d.vz[o],
+             s->id[c], s->id[o], d.posm};
+    const uint32_t *perm = s->vals[s->sorted_buf];
+    if (all_fields)
+        hipLaunchKernelGGL(k64_permute<true>, dim3(nblk(s->n, 256)), dim3(256), 0, s->stream, s->n, perm, a);
+    else
+        hipLaunchKernelGGL(k64_permute<false>, dim3(nblk(s->n, 256)), dim3(256), 0, s->stream, s->n, perm, a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // every pair flips; velocities not gathered are overwritten by the kick that ends the step
+    s->cur = o;
+    return hipSuccess;
+}
+
+hipError_t launch64_com(Sim *s)
+{
+    const int grid = std::min((2 * s->n + 255) / 256, 2048);
+    hipLaunchKernelGGL(k64_com, dim3(grid), dim3(256), 0, s->stream, s->counts, s->o_num_children,
+                       s->o_first_child, s->o_pb, s->o_pe, s->o_parent, s->d.posm, s->d.wsum,
+                       s->d.nodeA, s->com_counter);
+    return hipGetLastError();
+}
+
+hipError_t launch64_traverse(Sim *s, bool potential)
+{
+    State64 &d = s->d;
+    const int ngroups = (s->n + s->group - 1) / s->group;
+    if (ngroups < 1) return hipSuccess;
+    const int grid = (ngroups + T64_WAVES - 1) / T64_WAVES;
+    const double theta = (double) s->p.theta, eps = (double) s->p.softening_factor;
+    const double dom = (double) s->p.domain_size;
+#define NB_T64(GG, PP)                                                                           \
+    hipLaunchKernelGGL((k64_traverse<GG, PP>), dim3(grid), dim3(64 * T64_WAVES), 0, s->stream,    \
+                       s->n, ngroups, d.posm, d.nodeA, s->nodeB, theta * theta, eps * eps,        \
+                       (double) s->p.gravity, dom * dom * 3.0, d.ax, d.ay, d.az, d.pot,           \
+                       s->list_len, &s->counts->err)
+    if (s->group == 64) { if (potential) NB_T64(64, true); else NB_T64(64, false); }
+    else                { if (potential) NB_T64(32, true); else NB_T64(32, false); }
+#undef NB_T64
+    return hipGetLastError();
+}
+
+hipError_t launch64_vel_kick(Sim *s)
+{
+    State64 &d = s->d;
+    const int c = s->cur;
+    hipLaunchKernelGGL(k64_vel_kick, dim3(nblk(s->n, 256)), dim3(256), 0, s->stream, s->n,
+                       (double) s->p.dt, 1.0 - (double) s->p.velocity_dampening, d.vhx[c], d.vhy[c],
+                       d.vhz[c], d.ax, d.ay, d.az, d.vx[c], d.vy[c], d.vz[c]);
+    return hipGetLastError();
+}
+
+hipError_t launch64_export_view(Sim *s)
+{
+    if (!s->has_ext || s->n < 1) return hipSuccess;
+    State64 &d = s->d;
+    hipLaunchKernelGGL(k64_export_view, dim3(std::min(nblk(s->n, 256), 2048)), dim3(256), 0, s->stream,
+                       s->n, s->counts, d.posm, d.nodeA, s->nodeB, d.ext[0], d.ext[1], d.ext[2],
+                       d.ext[3], d.ext[4], d.ext[5], d.ext[6]);
+    return hipGetLastError();
+}
+
+hipError_t launch64_direct(const Double4 *targets, int nt, const Double4 *sources, int ns,
+                           double eps2, double gravity, double *ax, double *ay, double *az,
+                           double *pot, int self_pairs, hipStream_t st)
+{
+    if (nt <= 0) return hipSuccess;
+    if (pot)
+        hipLaunchKernelGGL(k64_direct<true>, dim3(nblk(nt, 256)), dim3(256), 0, st, targets, nt,
+                           sources, ns, eps2, gravity, ax, ay, az, pot, self_pairs);
+    else
+        hipLaunchKernelGGL(k64_direct<false>, dim3(nblk(nt, 256)), dim3(256), 0, st, targets, nt,
+                           sources, ns, eps2, gravity, ax, ay, az, pot, 0);
+    return hipGetLastError();
+}
+
+hipError_t launch64_twin_kick_drift(int n, double dt, double domain, Double4 *posm,
+                                    double *const v[3], double *const a[3], double *const vh[3],
+                                    hipStream_t st)
+{
+    hipLaunchKernelGGL(k64_twin_kick_drift, dim3(nblk(n, 256)), dim3(256), 0, st, n, dt, domain,
+                       posm, v[0], v[1], v[2], a[0], a[1], a[2], vh[0], vh[1], vh[2]);
+    return hipGetLastError();
+}
+
+hipError_t launch64_vel_kick_raw(int n, double dt, double keep, double *const vh[3],
+                                 double *const a[3], double *const v[3], hipStream_t st)
+{
+    hipLaunchKernelGGL(k64_vel_kick, dim3(nblk(n, 256)), dim3(256), 0, st, n, dt, keep, vh[0], vh[1],
+                       vh[2], a[0], a[1], a[2], v[0], v[1], v[2]);
+    return hipGetLastError();
+}
+
+}  // namespace nb

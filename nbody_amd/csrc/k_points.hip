@@ -12,29 +12,6 @@
 
 namespace nb {
 
-// 10-bit -> 30-bit spread (bit k -> bit 3k).
-__device__ __forceinline__ uint32_t spread3_10(uint32_t u)
-{
-    u &= 0x3ffu;
-    u = (u | (u << 16)) & 0x030000FFu;
-    u = (u | (u << 8)) & 0x0300F00Fu;
-    u = (u | (u << 4)) & 0x030C30C3u;
-    u = (u | (u << 2)) & 0x09249249u;
-    return u;
-}
-
-// 21-bit -> 63-bit spread (bit k -> bit 3k).
-__device__ __forceinline__ uint64_t spread3_21(uint64_t u)
-{
-    u &= 0x1fffffull;
-    u = (u | (u << 32)) & 0x001f00000000ffffull;
-    u = (u | (u << 16)) & 0x001f0000ff0000ffull;
-    u = (u | (u << 8)) & 0x100f00f00f00f00full;
-    u = (u | (u << 4)) & 0x10c30c30c30c30c3ull;
-    u = (u | (u << 2)) & 0x1249249249249249ull;
-    return u;
-}
-
 // q = (uint)(p / domain * (2^B - 1)): IEEE divide, then multiply, truncate.  The host
 // oracle performs the same two float operations; codes at cell boundaries depend on it.
 template <typename KeyT>

@@ -31,6 +31,7 @@ enum { EV_BEGIN = 0, EV_INTEGRATE, EV_SORT, EV_BUILD, EV_COM, EV_TRAVERSE,
        EV_COUNT };
 
 struct Float4 { float x, y, z, w; };
+struct Double4 { double x, y, z, w; };
 // Traversal record of an octree node.  Leaf: first/count = particle range, meta = NODE_LEAF.
 // Inner node: first/count = child range, meta bit c set iff child c is a leaf.
 struct NodeB { float size; int32_t first; int32_t count; uint32_t meta; };
@@ -58,8 +59,30 @@ struct Counts {
     int32_t pad[3];
 };
 
+// Floating-point state of a handle created with NBODY_FLAG_FP64 (the reference's
+// Simulation<double>, src/cuda/simulation.cu:256): the arrays a float handle keeps in Sim as
+// float, here in double.  Keys, the sort, every tree array, node sizes (domain / 2^level,
+// exact in float) and ids are shared with the float path.
+struct State64 {
+    double *x[2]{}, *y[2]{}, *z[2]{}, *m[2]{};
+    double *vhx[2]{}, *vhy[2]{}, *vhz[2]{};
+    double *vx[2]{}, *vy[2]{}, *vz[2]{};
+    double *ax = nullptr, *ay = nullptr, *az = nullptr;
+    Double4 *posm = nullptr;      // (x,y,z,m) in sorted order
+    Double4 *wsum = nullptr;      // unnormalised node sums
+    Double4 *nodeA = nullptr;     // (comx, comy, comz, mass)
+    double *pot = nullptr;
+    // validator twin (spawn order) and direct sum at the tree run's positions
+    Double4 *tw_posm = nullptr;
+    double *tw_v[3]{}, *tw_vh[3]{}, *tw_a[3]{}, *tw_pot = nullptr;
+    double *ds_a[3]{}, *ds_pot = nullptr;
+    double *ext[7]{};             // caller-owned viewer buffers, double
+};
+
 struct Sim {
     nbody_params p{};
+    bool fp64 = false;
+    State64 d;
     int n = 0;            // particles currently held (<= cap)
     int cap = 0;          // capacity every array is sized for (= params.num_points)
     int group = 64;
@@ -180,5 +203,23 @@ hipError_t launch_bbox(Sim *s, uint32_t *box_dev);
 hipError_t launch_let_export(Sim *s, const float *boxes_dev, int nboxes, Float4 *out, int cap,
                              uint32_t *out_count);
 hipError_t launch_unpack_sources(Sim *s, const Float4 *src, int n);
+
+
+// ---- double-precision handles (k_fp64.hip) ----
+hipError_t launch64_integrate_morton(Sim *s);
+hipError_t launch64_morton_only(Sim *s);
+hipError_t launch64_permute(Sim *s, bool all_fields);
+hipError_t launch64_com(Sim *s);
+hipError_t launch64_traverse(Sim *s, bool potential);       // -> d.ax/ay/az, or d.pot
+hipError_t launch64_vel_kick(Sim *s);
+hipError_t launch64_export_view(Sim *s);
+hipError_t launch64_direct(const Double4 *targets, int nt, const Double4 *sources, int ns,
+                           double eps2, double gravity, double *ax, double *ay, double *az,
+                           double *pot, int self_pairs, hipStream_t st);
+hipError_t launch64_twin_kick_drift(int n, double dt, double domain, Double4 *posm,
+                                    double *const v[3], double *const a[3], double *const vh[3],
+                                    hipStream_t st);
+hipError_t launch64_vel_kick_raw(int n, double dt, double keep, double *const vh[3],
+                                 double *const a[3], double *const v[3], hipStream_t st);
 
 }  // namespace nb

@@ -133,27 +133,30 @@ void set_node_child(const Keys &k, Btree &t, std::vector<int> &child, int parent
     }
 }
 
-// Pairwise softened force, float32.
+// Pairwise softened force in the precision T of the instantiation (the reference
+// instantiates every class for float and for double, src/cuda/simulation.cu:255-256).
 // include/cuda/physics_common.cuh:46-75 (accumulate_pairwise_force); the
-// reference's __frsqrt_rn is restated as 1/sqrt in float.
-inline void pair_force(float p1x, float p1y, float p1z, float p2x, float p2y, float p2z,
-                       float m2, float &fx, float &fy, float &fz, float eps2)
+// reference's rsqrt is restated as 1/sqrt in T.  std::fma / std::sqrt on float
+// arguments are fmaf / sqrtf.
+template <typename T>
+inline void pair_force(T p1x, T p1y, T p1z, T p2x, T p2y, T p2z, T m2, T &fx, T &fy, T &fz, T eps2)
 {
-    float dx = p2x - p1x, dy = p2y - p1y, dz = p2z - p1z;
-    float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-    float s = d2 + eps2;
-    float inv = 1.0f / sqrtf(s * s * s);
+    T dx = p2x - p1x, dy = p2y - p1y, dz = p2z - p1z;
+    T d2 = std::fma(dz, dz, std::fma(dy, dy, dx * dx));
+    T s = d2 + eps2;
+    T inv = T(1) / std::sqrt(s * s * s);
     inv *= m2;
-    fx = fmaf(dx, inv, fx);
-    fy = fmaf(dy, inv, fy);
-    fz = fmaf(dz, inv, fz);
+    fx = std::fma(dx, inv, fx);
+    fy = std::fma(dy, inv, fy);
+    fz = std::fma(dz, inv, fz);
 }
 
 // include/cuda/physics_common.cuh:36-44 (compute_dist_sq).
-inline float dist_sq(float ax, float ay, float az, float bx, float by, float bz)
+template <typename T>
+inline T dist_sq(T ax, T ay, T az, T bx, T by, T bz)
 {
-    float dx = ax - bx, dy = ay - by, dz = az - bz;
-    return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    T dx = ax - bx, dy = ay - by, dz = az - bz;
+    return std::fma(dz, dz, std::fma(dy, dy, dx * dx));
 }
 
 template <typename T>
@@ -169,6 +172,321 @@ static void permute(std::vector<T> &v, const std::vector<int32_t> &perm, std::ve
 }  // namespace
 
 extern "C" {
+void orc_sort(const uint64_t *codes, int n, uint64_t *sorted, int32_t *perm);
+int orc_unique(const uint64_t *sorted, int n, uint64_t *unique, int32_t *first_pt);
+int orc_coarsen(const uint64_t *unique, int U, int bits, int max_codes, int32_t *lfc);
+int orc_build_octree(const uint64_t *unique, int U, const int32_t *lfc, int M,
+                     const int32_t *first_pt, int bits, float domain, int32_t *first_child,
+                     int32_t *num_children, int32_t *leaves_begin, int32_t *leaves_end,
+                     int32_t *depth, int32_t *level, float *size, int32_t *points_begin,
+                     int32_t *points_end);
+}
+
+// ---------------------------------------------------------------------------
+// Floating-point stages, written once for the precision T of the instantiation
+// (float: Simulation<float>; double: Simulation<double>, src/cuda/simulation.cu:255-256).
+// The exported functions further down document each stage and cite its source.
+// ---------------------------------------------------------------------------
+namespace {
+
+template <typename T>
+void morton_impl(const T *x, const T *y, const T *z, int n, float domain, int bits,
+                 uint64_t *codes)
+{
+    const T scale = (T) ((1u << bits) - 1u);
+    const T dom = (T) domain;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        volatile T fx = x[i] / dom;
+        volatile T fy = y[i] / dom;
+        volatile T fz = z[i] / dom;
+        key_t_ qx = (key_t_) (fx * scale);
+        key_t_ qy = (key_t_) (fy * scale);
+        key_t_ qz = (key_t_) (fz * scale);
+        codes[i] = spread3(qx, bits) * 4 + spread3(qy, bits) * 2 + spread3(qz, bits);
+    }
+}
+
+template <typename T>
+void com_impl(int n_oct, const int32_t *first_child, const int32_t *num_children,
+              const int32_t *points_begin, const int32_t *points_end, const T *x, const T *y,
+              const T *z, const T *m, T *comx, T *comy, T *comz, T *mass)
+{
+    std::vector<T> wx(n_oct), wy(n_oct), wz(n_oct);
+    for (int o = n_oct - 1; o >= 0; --o) {
+        T sx = 0, sy = 0, sz = 0, sm = 0;
+        if (num_children[o] == 0) {
+            for (int p = points_begin[o]; p <= points_end[o]; ++p) {
+                T mp = m[p];
+                sx = std::fma(mp, x[p], sx);
+                sy = std::fma(mp, y[p], sy);
+                sz = std::fma(mp, z[p], sz);
+                sm += mp;
+            }
+        } else {
+            for (int c = first_child[o]; c < first_child[o] + num_children[o]; ++c) {
+                sx += wx[c]; sy += wy[c]; sz += wz[c]; sm += mass[c];
+            }
+        }
+        wx[o] = sx; wy[o] = sy; wz[o] = sz; mass[o] = sm;
+    }
+    for (int o = 0; o < n_oct; ++o) {
+        comx[o] = wx[o] / mass[o];
+        comy[o] = wy[o] / mass[o];
+        comz[o] = wz[o] / mass[o];
+    }
+}
+
+// Bodies (bx,by,bz; n of them, grouped by `group`) against the tree whose points are
+// (x,y,z,m).  orc_traverse passes the same arrays for both; orc_traverse_from passes the
+// bodies of one domain and the tree built over records imported from other domains.
+template <typename T>
+void traverse_core(int n, int group, const T *bx, const T *by, const T *bz, const T *x, const T *y,
+                   const T *z, const T *m, const int32_t *first_child,
+                   const int32_t *num_children, const int32_t *points_begin,
+                   const int32_t *points_end, const T *size, const T *comx, const T *comy,
+                   const T *comz, const T *mass, T theta, T eps2, T gravity, T domain, T *ax,
+                   T *ay, T *az, uint32_t *list_len, int accumulate)
+{
+    const int ngroups = (n + group - 1) / group;
+#pragma omp parallel
+    {
+        std::vector<int> stack;
+        std::vector<T> fx(group), fy(group), fz(group);
+#pragma omp for schedule(dynamic, 16)
+        for (int g = 0; g < ngroups; ++g) {
+            const int b0 = g * group, b1 = std::min(n, b0 + group);
+            std::fill(fx.begin(), fx.end(), T(0));
+            std::fill(fy.begin(), fy.end(), T(0));
+            std::fill(fz.begin(), fz.end(), T(0));
+            uint32_t cnt = 0;
+            stack.clear();
+            stack.push_back(0);
+            while (!stack.empty()) {
+                int node = stack.back();
+                stack.pop_back();
+                const int nc = num_children[node];
+                if (nc == 0) {
+                    for (int p = points_begin[node]; p <= points_end[node]; ++p) {
+                        for (int b = b0; b < b1; ++b)
+                            pair_force<T>(bx[b], by[b], bz[b], x[p], y[p], z[p], m[p], fx[b - b0],
+                                          fy[b - b0], fz[b - b0], eps2);
+                        ++cnt;
+                    }
+                    continue;
+                }
+                T dmin = domain * domain * T(3);
+                for (int b = b0; b < b1; ++b) {
+                    T d = dist_sq<T>(bx[b], by[b], bz[b], comx[node], comy[node], comz[node]);
+                    if (d <= dmin) dmin = d;
+                }
+                const T sz = size[node];
+                if (sz * sz / dmin < theta * theta) {
+                    for (int b = b0; b < b1; ++b)
+                        pair_force<T>(bx[b], by[b], bz[b], comx[node], comy[node], comz[node],
+                                      mass[node], fx[b - b0], fy[b - b0], fz[b - b0], eps2);
+                    ++cnt;
+                } else {
+                    for (int c = first_child[node] + nc - 1; c >= first_child[node]; --c)
+                        stack.push_back(c);
+                }
+            }
+            for (int b = b0; b < b1; ++b) {
+                T rx = gravity * fx[b - b0], ry = gravity * fy[b - b0], rz = gravity * fz[b - b0];
+                if (accumulate) { rx += ax[b]; ry += ay[b]; rz += az[b]; }
+                ax[b] = rx; ay[b] = ry; az[b] = rz;
+            }
+            list_len[g] = cnt;
+        }
+    }
+}
+
+template <typename T>
+inline void reflect(T &p, T &v, T domain)
+{
+    if (p < T(0) || p > domain) {
+        v *= T(-1);
+        p = std::max(T(0), std::min(domain, p));
+    }
+}
+
+template <typename T>
+void leapfrog_pos_impl(int n, T dt, T domain, T *x, T *y, T *z, const T *vx, const T *vy,
+                       const T *vz, const T *ax, const T *ay, const T *az, T *vhx, T *vhy, T *vhz)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        T hx = std::fma(T(0.5) * ax[i], dt, vx[i]);
+        T hy = std::fma(T(0.5) * ay[i], dt, vy[i]);
+        T hz = std::fma(T(0.5) * az[i], dt, vz[i]);
+        T px = std::fma(hx, dt, x[i]);
+        T py = std::fma(hy, dt, y[i]);
+        T pz = std::fma(hz, dt, z[i]);
+        reflect(px, hx, domain);
+        reflect(py, hy, domain);
+        reflect(pz, hz, domain);
+        x[i] = px; y[i] = py; z[i] = pz;
+        vhx[i] = hx; vhy[i] = hy; vhz[i] = hz;
+    }
+}
+
+template <typename T>
+void leapfrog_vel_impl(int n, T dt, T damp, const T *vhx, const T *vhy, const T *vhz, const T *ax,
+                       const T *ay, const T *az, T *vx, T *vy, T *vz)
+{
+    const T k = T(1) - damp;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        vx[i] = std::fma(T(0.5) * ax[i], dt, vhx[i]) * k;
+        vy[i] = std::fma(T(0.5) * ay[i], dt, vhy[i]) * k;
+        vz[i] = std::fma(T(0.5) * az[i], dt, vhz[i]) * k;
+    }
+}
+
+// Whole-step simulation object: the sequencing of Simulation<T>::update()
+// (src/cuda/simulation.cu:75-119,224-238) over the stage functions.  It is the
+// "multithreaded host build of the same algorithm" timed as the CPU baseline, and the
+// multi-step oracle for trajectory tests.
+template <typename T>
+struct OrcSimT {
+    int n, bits, max_codes, group;
+    float theta, dt, gravity, eps, domain, damp;   // Params stay float (include/simulation.hpp:21-26)
+    std::vector<T> x, y, z, m, vx, vy, vz, vhx, vhy, vhz, ax, ay, az;
+    std::vector<uint32_t> id;
+    // tree
+    std::vector<uint64_t> codes, sorted, unique;
+    std::vector<int32_t> perm, first_pt, lfc;
+    std::vector<int32_t> first_child, num_children, lb, le, depth, level, pb, pe;
+    std::vector<float> size_f;
+    std::vector<T> size, comx, comy, comz, mass;
+    std::vector<uint32_t> list_len;
+    int U = 0, M = 0, n_oct = 0;
+    double ms_build = 0, ms_traverse = 0, ms_integrate = 0;
+    uint64_t interactions = 0;
+};
+
+double now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// update_points + update_octree (src/cuda/simulation.cu:75-102).
+template <typename T>
+void sim_build(OrcSimT<T> *s, bool permute_all)
+{
+    const int n = s->n;
+    morton_impl<T>(s->x.data(), s->y.data(), s->z.data(), n, s->domain, s->bits, s->codes.data());
+    orc_sort(s->codes.data(), n, s->sorted.data(), s->perm.data());
+    std::vector<T> tf;
+    std::vector<uint32_t> ti;
+    permute(s->x, s->perm, tf); permute(s->y, s->perm, tf); permute(s->z, s->perm, tf);
+    permute(s->m, s->perm, tf);
+    permute(s->vhx, s->perm, tf); permute(s->vhy, s->perm, tf); permute(s->vhz, s->perm, tf);
+    permute(s->id, s->perm, ti);
+    if (permute_all) {  // src/cuda/barnes_hut.cu:577-587 gathers vel and acc too
+        permute(s->vx, s->perm, tf); permute(s->vy, s->perm, tf); permute(s->vz, s->perm, tf);
+        permute(s->ax, s->perm, tf); permute(s->ay, s->perm, tf); permute(s->az, s->perm, tf);
+    }
+    s->U = orc_unique(s->sorted.data(), n, s->unique.data(), s->first_pt.data());
+    s->M = orc_coarsen(s->unique.data(), s->U, s->bits, s->max_codes, s->lfc.data());
+    s->n_oct = orc_build_octree(s->unique.data(), s->U, s->lfc.data(), s->M, s->first_pt.data(),
+                                s->bits, s->domain, s->first_child.data(),
+                                s->num_children.data(), s->lb.data(), s->le.data(),
+                                s->depth.data(), s->level.data(), s->size_f.data(), s->pb.data(),
+                                s->pe.data());
+    // domain / 2^level: a power-of-two scaling of the float parameter, exact in T
+    for (int o = 0; o < s->n_oct; ++o) s->size[o] = (T) s->size_f[o];
+    com_impl<T>(s->n_oct, s->first_child.data(), s->num_children.data(), s->pb.data(),
+                s->pe.data(), s->x.data(), s->y.data(), s->z.data(), s->m.data(), s->comx.data(),
+                s->comy.data(), s->comz.data(), s->mass.data());
+}
+
+template <typename T>
+OrcSimT<T> *sim_create(int n, int bits, int max_codes, int group, float theta, float dt,
+                       float gravity, float eps, float domain, float damp, const T *x, const T *y,
+                       const T *z, const T *vx, const T *vy, const T *vz, const T *m)
+{
+    OrcSimT<T> *s = new OrcSimT<T>();
+    s->n = n; s->bits = bits; s->max_codes = max_codes; s->group = group;
+    s->theta = theta; s->dt = dt; s->gravity = gravity; s->eps = eps; s->domain = domain;
+    s->damp = damp;
+    auto cp = [&](std::vector<T> &d, const T *src) {
+        d.assign(n, T(0));
+        if (src) std::memcpy(d.data(), src, sizeof(T) * n);
+    };
+    cp(s->x, x); cp(s->y, y); cp(s->z, z); cp(s->vx, vx); cp(s->vy, vy); cp(s->vz, vz);
+    cp(s->m, m);
+    cp(s->vhx, nullptr); cp(s->vhy, nullptr); cp(s->vhz, nullptr);
+    cp(s->ax, nullptr); cp(s->ay, nullptr); cp(s->az, nullptr);
+    s->id.resize(n);
+    std::iota(s->id.begin(), s->id.end(), 0u);
+    s->codes.resize(n); s->sorted.resize(n); s->unique.resize(n);
+    s->perm.resize(n); s->first_pt.resize(n + 1); s->lfc.resize(n + 1);
+    const int cap = 2 * n;
+    s->first_child.resize(cap); s->num_children.resize(cap); s->lb.resize(cap);
+    s->le.resize(cap); s->depth.resize(cap); s->level.resize(cap); s->pb.resize(cap);
+    s->pe.resize(cap); s->size_f.resize(cap); s->size.resize(cap); s->comx.resize(cap);
+    s->comy.resize(cap); s->comz.resize(cap); s->mass.resize(cap);
+    s->list_len.resize((n + group - 1) / group);
+    // exec_post_spawn (src/cuda/simulation.cu:160-168): sort + tree, no forces.
+    sim_build(s, true);
+    return s;
+}
+
+// Simulation<T>::update (src/cuda/simulation.cu:224-238).
+template <typename T>
+void sim_step(OrcSimT<T> *s)
+{
+    double t0 = now_ms();
+    leapfrog_pos_impl<T>(s->n, (T) s->dt, (T) s->domain, s->x.data(), s->y.data(), s->z.data(),
+                         s->vx.data(), s->vy.data(), s->vz.data(), s->ax.data(), s->ay.data(),
+                         s->az.data(), s->vhx.data(), s->vhy.data(), s->vhz.data());
+    double t1 = now_ms();
+    sim_build(s, false);
+    double t2 = now_ms();
+    const T eps = (T) s->eps;
+    traverse_core<T>(s->n, s->group, s->x.data(), s->y.data(), s->z.data(), s->x.data(),
+                     s->y.data(), s->z.data(), s->m.data(), s->first_child.data(),
+                     s->num_children.data(), s->pb.data(), s->pe.data(), s->size.data(),
+                     s->comx.data(), s->comy.data(), s->comz.data(), s->mass.data(), (T) s->theta,
+                     eps * eps, (T) s->gravity, (T) s->domain, s->ax.data(), s->ay.data(),
+                     s->az.data(), s->list_len.data(), 0);
+    double t3 = now_ms();
+    leapfrog_vel_impl<T>(s->n, (T) s->dt, (T) s->damp, s->vhx.data(), s->vhy.data(), s->vhz.data(),
+                         s->ax.data(), s->ay.data(), s->az.data(), s->vx.data(), s->vy.data(),
+                         s->vz.data());
+    double t4 = now_ms();
+    s->ms_integrate = (t1 - t0) + (t4 - t3);
+    s->ms_build = t2 - t1;
+    s->ms_traverse = t3 - t2;
+    uint64_t inter = 0;
+    const int ng = (int) s->list_len.size();
+    for (int g = 0; g < ng; ++g) {
+        int nb = std::min(s->group, s->n - g * s->group);
+        inter += (uint64_t) s->list_len[g] * nb;
+    }
+    s->interactions = inter;
+}
+
+template <typename T>
+void sim_get_state(OrcSimT<T> *s, T *x, T *y, T *z, T *vx, T *vy, T *vz, T *m, T *ax, T *ay,
+                   T *az, uint32_t *id)
+{
+    auto cp = [&](T *d, const std::vector<T> &v) {
+        if (d) std::memcpy(d, v.data(), sizeof(T) * s->n);
+    };
+    cp(x, s->x); cp(y, s->y); cp(z, s->z); cp(vx, s->vx); cp(vy, s->vy); cp(vz, s->vz);
+    cp(m, s->m); cp(ax, s->ax); cp(ay, s->ay); cp(az, s->az);
+    if (id) std::memcpy(id, s->id.data(), sizeof(uint32_t) * s->n);
+}
+
+}  // namespace
+
+using OrcSim = OrcSimT<float>;
+using OrcSimD = OrcSimT<double>;
+
+extern "C" {
 
 // ---------------------------------------------------------------------------
 // Morton encode.  src/cuda/points.cu:16-38: q = (u64)(p / domain * (2^B-1))
@@ -178,17 +496,15 @@ extern "C" {
 void orc_morton(const float *x, const float *y, const float *z, int n, float domain, int bits,
                 uint64_t *codes)
 {
-    const float scale = (float) ((1u << bits) - 1u);
-#pragma omp parallel for schedule(static)
-    for (int i = 0; i < n; ++i) {
-        volatile float fx = x[i] / domain;
-        volatile float fy = y[i] / domain;
-        volatile float fz = z[i] / domain;
-        key_t_ qx = (key_t_) (fx * scale);
-        key_t_ qy = (key_t_) (fy * scale);
-        key_t_ qz = (key_t_) (fz * scale);
-        codes[i] = spread3(qx, bits) * 4 + spread3(qy, bits) * 2 + spread3(qz, bits);
-    }
+    morton_impl<float>(x, y, z, n, domain, bits, codes);
+}
+// The double instantiation: positions are double, `domain_size` stays a float and the
+// division and the multiplication by 2^B-1 are done in double (src/cuda/points.cu:28-30
+// with T = double).
+void orc_morton_dp(const double *x, const double *y, const double *z, int n, float domain,
+                   int bits, uint64_t *codes)
+{
+    morton_impl<double>(x, y, z, n, domain, bits, codes);
 }
 
 // ---------------------------------------------------------------------------
@@ -405,29 +721,16 @@ void orc_com(int n_oct, const int32_t *first_child, const int32_t *num_children,
              const float *y, const float *z, const float *m, float *comx, float *comy,
              float *comz, float *mass)
 {
-    std::vector<float> wx(n_oct), wy(n_oct), wz(n_oct);
-    for (int o = n_oct - 1; o >= 0; --o) {
-        float sx = 0.f, sy = 0.f, sz = 0.f, sm = 0.f;
-        if (num_children[o] == 0) {
-            for (int p = points_begin[o]; p <= points_end[o]; ++p) {
-                float mp = m[p];
-                sx = fmaf(mp, x[p], sx);
-                sy = fmaf(mp, y[p], sy);
-                sz = fmaf(mp, z[p], sz);
-                sm += mp;
-            }
-        } else {
-            for (int c = first_child[o]; c < first_child[o] + num_children[o]; ++c) {
-                sx += wx[c]; sy += wy[c]; sz += wz[c]; sm += mass[c];
-            }
-        }
-        wx[o] = sx; wy[o] = sy; wz[o] = sz; mass[o] = sm;
-    }
-    for (int o = 0; o < n_oct; ++o) {
-        comx[o] = wx[o] / mass[o];
-        comy[o] = wy[o] / mass[o];
-        comz[o] = wz[o] / mass[o];
-    }
+    com_impl<float>(n_oct, first_child, num_children, points_begin, points_end, x, y, z, m, comx,
+                    comy, comz, mass);
+}
+void orc_com_dp(int n_oct, const int32_t *first_child, const int32_t *num_children,
+                const int32_t *points_begin, const int32_t *points_end, const double *x,
+                const double *y, const double *z, const double *m, double *comx, double *comy,
+                double *comz, double *mass)
+{
+    com_impl<double>(n_oct, first_child, num_children, points_begin, points_end, x, y, z, m, comx,
+                     comy, comz, mass);
 }
 
 // ---------------------------------------------------------------------------
@@ -441,71 +744,6 @@ void orc_com(int n_oct, const int32_t *first_child, const int32_t *num_children,
 // first.  list_len[g] = number of (com|point) sources the group interacted
 // with; interactions = sum_g list_len[g] * bodies_in_group(g).
 // ---------------------------------------------------------------------------
-// Core: bodies (bx,by,bz; nb of them, grouped by `group`) against the tree whose points are
-// (x,y,z,m).  orc_traverse passes the same arrays for both; orc_traverse_from passes the
-// bodies of one domain and the tree built over records imported from other domains.
-static void traverse_core(int n, int group, const float *bx, const float *by, const float *bz,
-                          const float *x, const float *y, const float *z,
-                  const float *m, const int32_t *first_child,
-                  const int32_t *num_children, const int32_t *points_begin,
-                  const int32_t *points_end, const float *size, const float *comx,
-                  const float *comy, const float *comz, const float *mass, float theta,
-                  float eps2, float gravity, float domain, float *ax, float *ay, float *az,
-                  uint32_t *list_len, int accumulate)
-{
-    const int ngroups = (n + group - 1) / group;
-#pragma omp parallel
-    {
-        std::vector<int> stack;
-        std::vector<float> fx(group), fy(group), fz(group);
-#pragma omp for schedule(dynamic, 16)
-        for (int g = 0; g < ngroups; ++g) {
-            const int b0 = g * group, b1 = std::min(n, b0 + group);
-            std::fill(fx.begin(), fx.end(), 0.f);
-            std::fill(fy.begin(), fy.end(), 0.f);
-            std::fill(fz.begin(), fz.end(), 0.f);
-            uint32_t cnt = 0;
-            stack.clear();
-            stack.push_back(0);
-            while (!stack.empty()) {
-                int node = stack.back();
-                stack.pop_back();
-                const int nc = num_children[node];
-                if (nc == 0) {
-                    for (int p = points_begin[node]; p <= points_end[node]; ++p) {
-                        for (int b = b0; b < b1; ++b)
-                            pair_force(bx[b], by[b], bz[b], x[p], y[p], z[p], m[p], fx[b - b0],
-                                       fy[b - b0], fz[b - b0], eps2);
-                        ++cnt;
-                    }
-                    continue;
-                }
-                float dmin = domain * domain * 3.0f;
-                for (int b = b0; b < b1; ++b) {
-                    float d = dist_sq(bx[b], by[b], bz[b], comx[node], comy[node], comz[node]);
-                    if (d <= dmin) dmin = d;
-                }
-                const float sz = size[node];
-                if (sz * sz / dmin < theta * theta) {
-                    for (int b = b0; b < b1; ++b)
-                        pair_force(bx[b], by[b], bz[b], comx[node], comy[node], comz[node],
-                                   mass[node], fx[b - b0], fy[b - b0], fz[b - b0], eps2);
-                    ++cnt;
-                } else {
-                    for (int c = first_child[node] + nc - 1; c >= first_child[node]; --c)
-                        stack.push_back(c);
-                }
-            }
-            for (int b = b0; b < b1; ++b) {
-                float rx = gravity * fx[b - b0], ry = gravity * fy[b - b0], rz = gravity * fz[b - b0];
-                if (accumulate) { rx += ax[b]; ry += ay[b]; rz += az[b]; }
-                ax[b] = rx; ay[b] = ry; az[b] = rz;
-            }
-            list_len[g] = cnt;
-        }
-    }
-}
-
 void orc_traverse(int n, int group, const float *x, const float *y, const float *z,
                   const float *m, int n_oct, const int32_t *first_child,
                   const int32_t *num_children, const int32_t *points_begin,
@@ -515,9 +753,25 @@ void orc_traverse(int n, int group, const float *x, const float *y, const float 
                   uint32_t *list_len)
 {
     (void) n_oct;
-    traverse_core(n, group, x, y, z, x, y, z, m, first_child, num_children, points_begin,
-                  points_end, size, comx, comy, comz, mass, theta, eps2, gravity, domain, ax, ay,
-                  az, list_len, 0);
+    traverse_core<float>(n, group, x, y, z, x, y, z, m, first_child, num_children, points_begin,
+                         points_end, size, comx, comy, comz, mass, theta, eps2, gravity, domain, ax,
+                         ay, az, list_len, 0);
+}
+// T = double: theta, softening^2, gravity and the domain size are the float parameters
+// widened (the reference keeps Params in float for both instantiations,
+// include/simulation.hpp:21-26); node sizes are domain / 2^level, exact in either type.
+void orc_traverse_dp(int n, int group, const double *x, const double *y, const double *z,
+                     const double *m, int n_oct, const int32_t *first_child,
+                     const int32_t *num_children, const int32_t *points_begin,
+                     const int32_t *points_end, const double *size, const double *comx,
+                     const double *comy, const double *comz, const double *mass, double theta,
+                     double eps2, double gravity, double domain, double *ax, double *ay,
+                     double *az, uint32_t *list_len)
+{
+    (void) n_oct;
+    traverse_core<double>(n, group, x, y, z, x, y, z, m, first_child, num_children, points_begin,
+                          points_end, size, comx, comy, comz, mass, theta, eps2, gravity, domain,
+                          ax, ay, az, list_len, 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -534,9 +788,9 @@ void orc_traverse_from(int nb, int group, const float *bx, const float *by, cons
                        float gravity, float domain, float *ax, float *ay, float *az,
                        uint32_t *list_len, int accumulate)
 {
-    traverse_core(nb, group, bx, by, bz, x, y, z, m, first_child, num_children, points_begin,
-                  points_end, size, comx, comy, comz, mass, theta, eps2, gravity, domain, ax, ay,
-                  az, list_len, accumulate);
+    traverse_core<float>(nb, group, bx, by, bz, x, y, z, m, first_child, num_children,
+                         points_begin, points_end, size, comx, comy, comz, mass, theta, eps2,
+                         gravity, domain, ax, ay, az, list_len, accumulate);
 }
 
 // Records (x,y,z,m) a remote domain with bounding box `box` (lo xyz, hi xyz) needs from this
@@ -579,45 +833,18 @@ int orc_let_export(const int32_t *first_child, const int32_t *num_children,
 // x += v_half*dt; reflective walls flip the velocity component and clamp the
 // coordinate; v = (v_half + 0.5*a*dt) * (1 - damp).
 // ---------------------------------------------------------------------------
-static inline void reflect(float &p, float &v, float domain)
-{
-    if (p < 0.0f || p > domain) {
-        v *= -1.0f;
-        p = std::max(0.0f, std::min(domain, p));
-    }
-}
-
 void orc_leapfrog_pos(int n, float dt, float domain, float *x, float *y, float *z,
                       const float *vx, const float *vy, const float *vz, const float *ax,
                       const float *ay, const float *az, float *vhx, float *vhy, float *vhz)
 {
-#pragma omp parallel for schedule(static)
-    for (int i = 0; i < n; ++i) {
-        float hx = fmaf(0.5f * ax[i], dt, vx[i]);
-        float hy = fmaf(0.5f * ay[i], dt, vy[i]);
-        float hz = fmaf(0.5f * az[i], dt, vz[i]);
-        float px = fmaf(hx, dt, x[i]);
-        float py = fmaf(hy, dt, y[i]);
-        float pz = fmaf(hz, dt, z[i]);
-        reflect(px, hx, domain);
-        reflect(py, hy, domain);
-        reflect(pz, hz, domain);
-        x[i] = px; y[i] = py; z[i] = pz;
-        vhx[i] = hx; vhy[i] = hy; vhz[i] = hz;
-    }
+    leapfrog_pos_impl<float>(n, dt, domain, x, y, z, vx, vy, vz, ax, ay, az, vhx, vhy, vhz);
 }
 
 void orc_leapfrog_vel(int n, float dt, float damp, const float *vhx, const float *vhy,
                       const float *vhz, const float *ax, const float *ay, const float *az,
                       float *vx, float *vy, float *vz)
 {
-    const float k = 1.0f - damp;
-#pragma omp parallel for schedule(static)
-    for (int i = 0; i < n; ++i) {
-        vx[i] = fmaf(0.5f * ax[i], dt, vhx[i]) * k;
-        vy[i] = fmaf(0.5f * ay[i], dt, vhy[i]) * k;
-        vz[i] = fmaf(0.5f * az[i], dt, vhz[i]) * k;
-    }
+    leapfrog_vel_impl<float>(n, dt, damp, vhx, vhy, vhz, ax, ay, az, vx, vy, vz);
 }
 
 // ---------------------------------------------------------------------------
@@ -703,142 +930,84 @@ void orc_acc_error(int k, const float *ax, const float *ay, const float *az, con
 // is the "multithreaded host build of the same algorithm" timed as the CPU
 // baseline, and the multi-step oracle for trajectory tests.
 // ---------------------------------------------------------------------------
-struct OrcSim {
-    int n, bits, max_codes, group;
-    float theta, dt, gravity, eps, domain, damp;
-    std::vector<float> x, y, z, m, vx, vy, vz, vhx, vhy, vhz, ax, ay, az;
-    std::vector<uint32_t> id;
-    // tree
-    std::vector<uint64_t> codes, sorted, unique;
-    std::vector<int32_t> perm, first_pt, lfc;
-    std::vector<int32_t> first_child, num_children, lb, le, depth, level, pb, pe;
-    std::vector<float> size, comx, comy, comz, mass;
-    std::vector<uint32_t> list_len;
-    int U = 0, M = 0, n_oct = 0;
-    double ms_build = 0, ms_traverse = 0, ms_integrate = 0;
-    uint64_t interactions = 0;
-};
-
-static double now_ms()
-{
-    using namespace std::chrono;
-    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
-}
-
-// update_points + update_octree (src/cuda/simulation.cu:75-102).
-static void orc_sim_build(OrcSim *s, bool permute_all)
-{
-    const int n = s->n;
-    orc_morton(s->x.data(), s->y.data(), s->z.data(), n, s->domain, s->bits, s->codes.data());
-    orc_sort(s->codes.data(), n, s->sorted.data(), s->perm.data());
-    std::vector<float> tf;
-    std::vector<uint32_t> ti;
-    permute(s->x, s->perm, tf); permute(s->y, s->perm, tf); permute(s->z, s->perm, tf);
-    permute(s->m, s->perm, tf);
-    permute(s->vhx, s->perm, tf); permute(s->vhy, s->perm, tf); permute(s->vhz, s->perm, tf);
-    permute(s->id, s->perm, ti);
-    if (permute_all) {  // src/cuda/barnes_hut.cu:577-587 gathers vel and acc too
-        permute(s->vx, s->perm, tf); permute(s->vy, s->perm, tf); permute(s->vz, s->perm, tf);
-        permute(s->ax, s->perm, tf); permute(s->ay, s->perm, tf); permute(s->az, s->perm, tf);
-    }
-    s->U = orc_unique(s->sorted.data(), n, s->unique.data(), s->first_pt.data());
-    s->M = orc_coarsen(s->unique.data(), s->U, s->bits, s->max_codes, s->lfc.data());
-    s->n_oct = orc_build_octree(s->unique.data(), s->U, s->lfc.data(), s->M, s->first_pt.data(),
-                                s->bits, s->domain, s->first_child.data(),
-                                s->num_children.data(), s->lb.data(), s->le.data(),
-                                s->depth.data(), s->level.data(), s->size.data(), s->pb.data(),
-                                s->pe.data());
-    orc_com(s->n_oct, s->first_child.data(), s->num_children.data(), s->pb.data(), s->pe.data(),
-            s->x.data(), s->y.data(), s->z.data(), s->m.data(), s->comx.data(), s->comy.data(),
-            s->comz.data(), s->mass.data());
-}
-
 OrcSim *orc_sim_create(int n, int bits, int max_codes, int group, float theta, float dt,
                        float gravity, float eps, float domain, float damp, const float *x,
                        const float *y, const float *z, const float *vx, const float *vy,
                        const float *vz, const float *m)
 {
-    OrcSim *s = new OrcSim();
-    s->n = n; s->bits = bits; s->max_codes = max_codes; s->group = group;
-    s->theta = theta; s->dt = dt; s->gravity = gravity; s->eps = eps; s->domain = domain;
-    s->damp = damp;
-    auto cp = [&](std::vector<float> &d, const float *src) {
-        d.assign(n, 0.f);
-        if (src) std::memcpy(d.data(), src, sizeof(float) * n);
-    };
-    cp(s->x, x); cp(s->y, y); cp(s->z, z); cp(s->vx, vx); cp(s->vy, vy); cp(s->vz, vz);
-    cp(s->m, m);
-    cp(s->vhx, nullptr); cp(s->vhy, nullptr); cp(s->vhz, nullptr);
-    cp(s->ax, nullptr); cp(s->ay, nullptr); cp(s->az, nullptr);
-    s->id.resize(n);
-    std::iota(s->id.begin(), s->id.end(), 0u);
-    s->codes.resize(n); s->sorted.resize(n); s->unique.resize(n);
-    s->perm.resize(n); s->first_pt.resize(n + 1); s->lfc.resize(n + 1);
-    const int cap = 2 * n;
-    s->first_child.resize(cap); s->num_children.resize(cap); s->lb.resize(cap);
-    s->le.resize(cap); s->depth.resize(cap); s->level.resize(cap); s->pb.resize(cap);
-    s->pe.resize(cap); s->size.resize(cap); s->comx.resize(cap); s->comy.resize(cap);
-    s->comz.resize(cap); s->mass.resize(cap);
-    s->list_len.resize((n + group - 1) / group);
-    // exec_post_spawn (src/cuda/simulation.cu:160-168): sort + tree, no forces.
-    orc_sim_build(s, true);
-    return s;
+    return sim_create<float>(n, bits, max_codes, group, theta, dt, gravity, eps, domain, damp, x, y,
+                             z, vx, vy, vz, m);
 }
-
 void orc_sim_destroy(OrcSim *s) { delete s; }
-
-// Simulation<T>::update (src/cuda/simulation.cu:224-238).
-void orc_sim_step(OrcSim *s)
-{
-    double t0 = now_ms();
-    orc_leapfrog_pos(s->n, s->dt, s->domain, s->x.data(), s->y.data(), s->z.data(),
-                     s->vx.data(), s->vy.data(), s->vz.data(), s->ax.data(), s->ay.data(),
-                     s->az.data(), s->vhx.data(), s->vhy.data(), s->vhz.data());
-    double t1 = now_ms();
-    orc_sim_build(s, false);
-    double t2 = now_ms();
-    orc_traverse(s->n, s->group, s->x.data(), s->y.data(), s->z.data(), s->m.data(), s->n_oct,
-                 s->first_child.data(), s->num_children.data(), s->pb.data(), s->pe.data(),
-                 s->size.data(), s->comx.data(), s->comy.data(), s->comz.data(),
-                 s->mass.data(), s->theta, s->eps * s->eps, s->gravity, s->domain,
-                 s->ax.data(), s->ay.data(), s->az.data(), s->list_len.data());
-    double t3 = now_ms();
-    orc_leapfrog_vel(s->n, s->dt, s->damp, s->vhx.data(), s->vhy.data(), s->vhz.data(),
-                     s->ax.data(), s->ay.data(), s->az.data(), s->vx.data(), s->vy.data(),
-                     s->vz.data());
-    double t4 = now_ms();
-    s->ms_integrate = (t1 - t0) + (t4 - t3);
-    s->ms_build = t2 - t1;
-    s->ms_traverse = t3 - t2;
-    uint64_t inter = 0;
-    const int ng = (int) s->list_len.size();
-    for (int g = 0; g < ng; ++g) {
-        int nb = std::min(s->group, s->n - g * s->group);
-        inter += (uint64_t) s->list_len[g] * nb;
-    }
-    s->interactions = inter;
-}
-
+void orc_sim_step(OrcSim *s) { sim_step(s); }
 void orc_sim_get_state(OrcSim *s, float *x, float *y, float *z, float *vx, float *vy, float *vz,
                        float *m, float *ax, float *ay, float *az, uint32_t *id)
 {
-    auto cp = [&](float *d, const std::vector<float> &v) {
-        if (d) std::memcpy(d, v.data(), sizeof(float) * s->n);
-    };
-    cp(x, s->x); cp(y, s->y); cp(z, s->z); cp(vx, s->vx); cp(vy, s->vy); cp(vz, s->vz);
-    cp(m, s->m); cp(ax, s->ax); cp(ay, s->ay); cp(az, s->az);
-    if (id) std::memcpy(id, s->id.data(), sizeof(uint32_t) * s->n);
+    sim_get_state(s, x, y, z, vx, vy, vz, m, ax, ay, az, id);
 }
-
 void orc_sim_get_counts(OrcSim *s, int32_t *U, int32_t *M, int32_t *n_oct,
                         uint64_t *interactions)
 {
     *U = s->U; *M = s->M; *n_oct = s->n_oct; *interactions = s->interactions;
 }
-
 void orc_sim_get_timings(OrcSim *s, double *ms_integrate, double *ms_build, double *ms_traverse)
 {
     *ms_integrate = s->ms_integrate; *ms_build = s->ms_build; *ms_traverse = s->ms_traverse;
+}
+
+// Simulation<double> (src/cuda/simulation.cu:256): the same object with every float array
+// and every floating-point operation in double.
+OrcSimD *orc_sim_create_dp(int n, int bits, int max_codes, int group, float theta, float dt,
+                           float gravity, float eps, float domain, float damp, const double *x,
+                           const double *y, const double *z, const double *vx, const double *vy,
+                           const double *vz, const double *m)
+{
+    return sim_create<double>(n, bits, max_codes, group, theta, dt, gravity, eps, domain, damp, x,
+                              y, z, vx, vy, vz, m);
+}
+void orc_sim_destroy_dp(OrcSimD *s) { delete s; }
+void orc_sim_step_dp(OrcSimD *s) { sim_step(s); }
+void orc_sim_get_state_dp(OrcSimD *s, double *x, double *y, double *z, double *vx, double *vy,
+                          double *vz, double *m, double *ax, double *ay, double *az, uint32_t *id)
+{
+    sim_get_state(s, x, y, z, vx, vy, vz, m, ax, ay, az, id);
+}
+void orc_sim_get_counts_dp(OrcSimD *s, int32_t *U, int32_t *M, int32_t *n_oct,
+                           uint64_t *interactions)
+{
+    *U = s->U; *M = s->M; *n_oct = s->n_oct; *interactions = s->interactions;
+}
+// Tree products of the last build: integer arrays as in orc_build_octree, centres of mass in double.
+void orc_sim_get_tree_dp(OrcSimD *s, uint64_t *sorted, int32_t *first_child, int32_t *num_children,
+                         int32_t *points_begin, int32_t *points_end, double *comx, double *comy,
+                         double *comz, double *mass, uint32_t *list_len)
+{
+    if (sorted) std::memcpy(sorted, s->sorted.data(), sizeof(uint64_t) * s->n);
+    const size_t no = (size_t) s->n_oct;
+    if (first_child) std::memcpy(first_child, s->first_child.data(), 4 * no);
+    if (num_children) std::memcpy(num_children, s->num_children.data(), 4 * no);
+    if (points_begin) std::memcpy(points_begin, s->pb.data(), 4 * no);
+    if (points_end) std::memcpy(points_end, s->pe.data(), 4 * no);
+    if (comx) std::memcpy(comx, s->comx.data(), 8 * no);
+    if (comy) std::memcpy(comy, s->comy.data(), 8 * no);
+    if (comz) std::memcpy(comz, s->comz.data(), 8 * no);
+    if (mass) std::memcpy(mass, s->mass.data(), 8 * no);
+    if (list_len) std::memcpy(list_len, s->list_len.data(), 4 * s->list_len.size());
+}
+
+// All-pairs accelerations of double-precision particles, in double (src/cuda/validator.cu:
+// 134-174 with T = double).
+void orc_direct_dp(int n, int t0, int t1, const double *x, const double *y, const double *z,
+                   const double *m, double eps2, double gravity, double *ax, double *ay,
+                   double *az)
+{
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int i = t0; i < t1; ++i) {
+        double fx = 0, fy = 0, fz = 0;
+        for (int j = 0; j < n; ++j)
+            pair_force<double>(x[i], y[i], z[i], x[j], y[j], z[j], m[j], fx, fy, fz, eps2);
+        ax[i - t0] = gravity * fx; ay[i - t0] = gravity * fy; az[i - t0] = gravity * fz;
+    }
 }
 
 int orc_num_threads(void)

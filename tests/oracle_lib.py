@@ -36,6 +36,7 @@ def lib() -> C.CDLL:
     L.orc_sim_create.restype = C.c_void_p
     L.orc_num_threads.restype = C.c_int
     L.orc_let_export.restype = C.c_int
+    L.orc_sim_create_dp.restype = C.c_void_p
     _lib = L
     return L
 
@@ -260,6 +261,128 @@ class OracleSim:
     def close(self):
         if self._h:
             lib().orc_sim_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- double-precision instantiation (Simulation<double>, src/cuda/simulation.cu:256) ----
+
+def _f64(a):
+    return np.ascontiguousarray(a, np.float64)
+
+
+def morton_dp(x, y, z, domain, bits):
+    x, y, z = _f64(x), _f64(y), _f64(z)
+    codes = np.empty(x.size, np.uint64)
+    lib().orc_morton_dp(_p(x), _p(y), _p(z), C.c_int(x.size), C.c_float(domain), C.c_int(bits), _p(codes))
+    return codes
+
+
+def com_dp(tree, x, y, z, m):
+    n_oct = tree["n_oct"]
+    x, y, z, m = _f64(x), _f64(y), _f64(z), _f64(m)
+    out = {k: np.empty(n_oct, np.float64) for k in ("comx", "comy", "comz", "mass")}
+    lib().orc_com_dp(C.c_int(n_oct), _p(tree["first_child"]), _p(tree["num_children"]),
+                     _p(tree["points_begin"]), _p(tree["points_end"]), _p(x), _p(y), _p(z), _p(m),
+                     _p(out["comx"]), _p(out["comy"]), _p(out["comz"]), _p(out["mass"]))
+    return out
+
+
+def traverse_dp(tree, comd, x, y, z, m, group, theta, eps, gravity, domain):
+    """theta, eps, gravity, domain are the float32 parameters, widened like the library does."""
+    x, y, z, m = _f64(x), _f64(y), _f64(z), _f64(m)
+    n = x.size
+    ax, ay, az = (np.empty(n, np.float64) for _ in range(3))
+    ll = np.empty((n + group - 1) // group, np.uint32)
+    a = {k: _f64(comd[k]) for k in ("comx", "comy", "comz", "mass")}
+    size = _f64(tree["size"])
+    e = float(np.float32(eps))
+    lib().orc_traverse_dp(C.c_int(n), C.c_int(group), _p(x), _p(y), _p(z), _p(m),
+                          C.c_int(tree["n_oct"]), _p(np.ascontiguousarray(tree["first_child"], np.int32)),
+                          _p(np.ascontiguousarray(tree["num_children"], np.int32)),
+                          _p(np.ascontiguousarray(tree["points_begin"], np.int32)),
+                          _p(np.ascontiguousarray(tree["points_end"], np.int32)), _p(size),
+                          _p(a["comx"]), _p(a["comy"]), _p(a["comz"]), _p(a["mass"]),
+                          C.c_double(float(np.float32(theta))), C.c_double(e * e),
+                          C.c_double(float(np.float32(gravity))), C.c_double(float(np.float32(domain))),
+                          _p(ax), _p(ay), _p(az), _p(ll))
+    return ax, ay, az, ll
+
+
+def direct_dp(x, y, z, m, eps, gravity, t0=0, t1=None):
+    x, y, z, m = _f64(x), _f64(y), _f64(z), _f64(m)
+    n = x.size
+    t1 = n if t1 is None else t1
+    out = [np.empty(t1 - t0, np.float64) for _ in range(3)]
+    e = float(np.float32(eps))
+    lib().orc_direct_dp(C.c_int(n), C.c_int(t0), C.c_int(t1), _p(x), _p(y), _p(z), _p(m),
+                        C.c_double(e * e), C.c_double(float(np.float32(gravity))), *[_p(o) for o in out])
+    return out
+
+
+def full_build_dp(x, y, z, m, domain, bits, max_codes):
+    """full_build for double-precision particles: same integer stages, COM in double."""
+    codes = morton_dp(x, y, z, domain, bits)
+    sorted_codes, perm = sort(codes)
+    xs, ys, zs, ms = (_f64(a)[perm] for a in (x, y, z, m))
+    uq, first_pt = unique(sorted_codes)
+    lfc = coarsen(uq, bits, max_codes)
+    tree = build_octree(uq, lfc, first_pt, bits, domain)
+    comd = com_dp(tree, xs, ys, zs, ms)
+    return dict(codes=codes, codes_sorted=sorted_codes, perm=perm, unique=uq, first_pt=first_pt,
+                leaf_first_code_idx=lfc, tree=tree, com=comd, xs=xs, ys=ys, zs=zs, ms=ms)
+
+
+class OracleSimDP:
+    """OracleSim with every floating-point array and operation in double."""
+
+    def __init__(self, x, y, z, m, vx=None, vy=None, vz=None, *, bits=10, max_codes=32, group=64,
+                 theta=0.75, dt=1e-4, gravity=1.0, eps=1e-3, domain=5.0, damp=0.0):
+        self.n = len(x)
+        arrs = [_f64(a) if a is not None else None for a in (x, y, z, vx, vy, vz, m)]
+        self._h = C.c_void_p(lib().orc_sim_create_dp(
+            C.c_int(self.n), C.c_int(bits), C.c_int(max_codes), C.c_int(group), C.c_float(theta),
+            C.c_float(dt), C.c_float(gravity), C.c_float(eps), C.c_float(domain), C.c_float(damp),
+            *[_p(a) for a in arrs]))
+
+    def step(self):
+        lib().orc_sim_step_dp(self._h)
+
+    def state(self):
+        names = ("x", "y", "z", "vx", "vy", "vz", "m", "ax", "ay", "az")
+        out = {k: np.empty(self.n, np.float64) for k in names}
+        out["id"] = np.empty(self.n, np.uint32)
+        lib().orc_sim_get_state_dp(self._h, *[_p(out[k]) for k in names], _p(out["id"]))
+        return out
+
+    def counts(self):
+        U, M, no, it = C.c_int32(), C.c_int32(), C.c_int32(), C.c_uint64()
+        lib().orc_sim_get_counts_dp(self._h, C.byref(U), C.byref(M), C.byref(no), C.byref(it))
+        return U.value, M.value, no.value, it.value
+
+    def tree(self):
+        U, M, no, _ = self.counts()
+        out = dict(codes_sorted=np.empty(self.n, np.uint64))
+        for k in ("first_child", "num_children", "points_begin", "points_end"):
+            out[k] = np.empty(no, np.int32)
+        for k in ("comx", "comy", "comz", "mass"):
+            out[k] = np.empty(no, np.float64)
+        ng = 0
+        out["list_len"] = None
+        lib().orc_sim_get_tree_dp(self._h, _p(out["codes_sorted"]), _p(out["first_child"]),
+                                  _p(out["num_children"]), _p(out["points_begin"]),
+                                  _p(out["points_end"]), _p(out["comx"]), _p(out["comy"]),
+                                  _p(out["comz"]), _p(out["mass"]), None)
+        return out
+
+    def close(self):
+        if self._h:
+            lib().orc_sim_destroy_dp(self._h)
             self._h = None
 
     def __del__(self):
