@@ -40,6 +40,7 @@ DT = 1e-6
 FLOP_PER_INTERACTION = 20          # GPU-Gems/Nyland convention for one softened pair force
 BUILD_BYTES_PER_PARTICLE = 300     # algorithmic bytes of integrate+sort+permute+build+COM
 PEAK_FP32_TFLOPS = 157.3           # MI355X FP32 vector peak
+PEAK_FP64_TFLOPS = 78.6            # MI355X FP64 vector peak
 PEAK_HBM_GBS = 8000.0              # MI355X HBM3E peak
 SUSTAINED_CLOCK_GHZ = 2.0          # shader clock measured inside k_traverse (profiles/r1_walk_profile.txt)
 REFERENCE_MS_PER_STEP = 150.0      # reference README, RTX 500 Ada, 2,097,152 particles, theta=0.6
@@ -349,6 +350,26 @@ def main():
         g32 = {"traversal_group_size": 32, "ms_per_step": round((tb - ta) * 1e3 / 20, 4),
                "traversal_ms": round(t5["ms_traverse"] / 20, 4),
                "interactions_per_step": round(t5["interactions"] / 20)}
+    f64 = None
+    if world == 1 and not args.no_alt_bits and not args.walk_only:
+        # the reference's Simulation<double> on the same particles, for the record
+        p6 = nb.Params(**{**params.__dict__, "flags": nb.FLAG_TIMING | nb.FLAG_FP64})
+        with nb.Simulation(p6) as s6:
+            s6.set_state(ic["x"], ic["y"], ic["z"], ic["m"])
+            s6.step(2)
+            s6.get_timings()
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            s6.step(10)
+            s6.sync()
+            tb = time.perf_counter()
+            t6 = s6.get_timings()
+        tf64 = FLOP_PER_INTERACTION * t6["interactions"] / (t6["ms_traverse"] * 1e-3) / 1e12
+        f64 = {"dtype": "f64", "ms_per_step": round((tb - ta) * 1e3 / 10, 4),
+               "traversal_ms": round(t6["ms_traverse"] / 10, 4),
+               "interactions_per_step": round(t6["interactions"] / 10),
+               "traversal_tflops": round(tf64, 2), "peak_fp64_vector_tflops": PEAK_FP64_TFLOPS,
+               "frac": round(tf64 / PEAK_FP64_TFLOPS, 4)}
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
@@ -435,6 +456,8 @@ def main():
             out["other_key_width"] = alt
         if g32 is not None:
             out["other_group_size"] = g32
+        if f64 is not None:
+            out["other_precision"] = f64
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ic, args.morton_bits, eps=eps)
         print(json.dumps(out))

@@ -8,7 +8,8 @@
 // caller-owned device buffers that receive positions and octree centres of mass / sizes
 // after every update; device_view() reads the library's own buffers in place.
 // Errors, which the reference silently ignores, throw std::runtime_error.
-// Only T = float exists (the reference's shipped SIM_PRECISION, include/renderer.hpp:14).
+// T = float (the reference's shipped SIM_PRECISION, include/renderer.hpp:14) or double
+// (src/cuda/simulation.cu:255-256): Simulation<double> creates its handle with NBODY_FLAG_FP64.
 #ifndef NBODY_SIMULATION_HPP
 #define NBODY_SIMULATION_HPP
 
@@ -21,7 +22,8 @@
 
 template <typename T>
 class Simulation {
-    static_assert(std::is_same<T, float>::value, "libnbody_mi355 implements Simulation<float>");
+    static_assert(std::is_same<T, float>::value || std::is_same<T, double>::value,
+                  "libnbody_mi355 implements Simulation<float> and Simulation<double>");
 
 public:
     struct Params {
@@ -44,7 +46,7 @@ public:
         : Simulation(params, nullptr, morton_bits, device_id, flags)
     {
     }
-    // buffers: [pos.x, pos.y, pos.z, com.x, com.y, com.z, node_size], device pointers to float
+    // buffers: [pos.x, pos.y, pos.z, com.x, com.y, com.z, node_size], device pointers to T
     // (include/simulation.hpp:31); see nbody_create_external for sizes.
     Simulation(Params &params, void *buffers[7], int morton_bits = 21, int device_id = -1,
                unsigned flags = 0)
@@ -65,7 +67,7 @@ public:
         p.num_steps_validator = params.num_steps_validator;
         p.morton_bits = morton_bits;
         p.device_id = device_id;
-        p.flags = flags;
+        p.flags = flags | (std::is_same<T, double>::value ? (unsigned) NBODY_FLAG_FP64 : 0u);
         const int rc = nbody_create_external(&p, buffers, &sim_);
         if (rc != NBODY_OK) throw std::runtime_error("nbody_create failed, status " + std::to_string(rc));
     }
@@ -90,11 +92,19 @@ public:
 
     // additions over the reference
     nbody_t *handle() { return sim_; }
-    nbody_dev_view device_view()
+    // the library's own arrays in place: nbody_dev_view for float, nbody_dev_view_f64 for double
+    typename std::conditional<std::is_same<T, double>::value, nbody_dev_view_f64, nbody_dev_view>::type
+    device_view()
     {
-        nbody_dev_view v;
-        check(nbody_get_device_ptrs(sim_, &v));
-        return v;
+        if constexpr (std::is_same<T, double>::value) {
+            nbody_dev_view_f64 v;
+            check(nbody_get_device_ptrs_f64(sim_, &v));
+            return v;
+        } else {
+            nbody_dev_view v;
+            check(nbody_get_device_ptrs(sim_, &v));
+            return v;
+        }
     }
 
 private:

@@ -33,6 +33,17 @@ def test_cpp_mirror_example_runs():
         sim.step(3)
         assert sim.get_num_octree_nodes() == int(m.group(1))
         assert abs(sim.get_state()["x"].mean() - float(m.group(3))) < 1e-4
+    # Simulation<double>
+    out = subprocess.run([exe, "disk", "16384", "3", "21", "double"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    m = re.search(r"precision=double octree_nodes=(\d+) ms_per_step=([0-9.]+) mean_x=([0-9.]+)", out.stdout)
+    assert m, out.stdout
+    with nb.Simulation(nb.Params(num_points=16384, morton_bits=21, theta=0.75, dt=1e-4,
+                                 softening_factor=0.001, flags=nb.FLAG_FP64)) as sim:
+        sim.spawn_disk()
+        sim.step(3)
+        assert sim.get_num_octree_nodes() == int(m.group(1))
+        assert abs(sim.get_state()["x"].mean() - float(m.group(3))) < 1e-8
 
 
 @pytest.fixture(scope="module")

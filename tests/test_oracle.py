@@ -333,3 +333,77 @@ def test_config1_host_plumbing_energy_and_accuracy():
     rx, ry, rz = O.direct_f64(s["x"], s["y"], s["z"], s["m"], eps, 1.0)
     mean, _ = O.acc_error(s["ax"], s["ay"], s["az"], rx, ry, rz)
     assert mean < 8e-4
+
+
+# ------------------------------------------------------------------ double instantiation
+def test_dp_morton_divides_and_scales_in_double():
+    """src/cuda/points.cu:28-30 with T = double: q = (u64)(p / domain * (2^B-1)) in double."""
+    rng = np.random.default_rng(11)
+    x, y, z = rng.uniform(0, 5, (3, 2000))
+    for bits in (10, 21):
+        s = float((1 << bits) - 1)
+        want = [spread3_py(int(px / 5.0 * s), bits) * 4 + spread3_py(int(py / 5.0 * s), bits) * 2 +
+                spread3_py(int(pz / 5.0 * s), bits) for px, py, pz in zip(x, y, z)]
+        assert list(O.morton_dp(x, y, z, 5.0, bits)) == want
+    # a coordinate whose float and double quotients land in different cells
+    p = np.array([np.nextafter(5.0 * 1000 / 2097151, 0.0)])
+    zero = np.zeros(1)
+    assert int(O.morton_dp(zero, zero, p, 5.0, 21)[0]) == spread3_py(999, 21)
+    assert int(O.morton(zero, zero, p.astype(np.float32), 5.0, 21)[0]) in (spread3_py(999, 21), spread3_py(1000, 21))
+
+
+def test_dp_stages_agree_with_float_stages_to_float_rounding():
+    rng = np.random.default_rng(12)
+    n = 3000
+    pts = rng.uniform(1.5, 3.5, (n, 3)).astype(np.float32)   # float-representable input
+    m = rng.uniform(0.5, 1.5, n).astype(np.float32)
+    bf = O.full_build(pts[:, 0], pts[:, 1], pts[:, 2], m, 5.0, 10, 8)
+    bd = O.full_build_dp(pts[:, 0], pts[:, 1], pts[:, 2], m, 5.0, 10, 8)
+    # 10-bit cells are far coarser than float rounding of p/domain: the same tree
+    assert np.array_equal(bf["codes_sorted"], bd["codes_sorted"])
+    assert bd["com"]["comx"].dtype == np.float64
+    assert np.allclose(bf["com"]["comx"], bd["com"]["comx"], rtol=2e-6)
+    o = bd["tree"]["n_oct"] // 2
+    sl = slice(bd["tree"]["points_begin"][o], bd["tree"]["points_end"][o] + 1)
+    mm = bd["ms"][sl]
+    assert np.isclose(bd["com"]["comy"][o], (mm * bd["ys"][sl]).sum() / mm.sum(), rtol=1e-14)
+    ax, ay, az, ll = O.traverse(bf["tree"], bf["com"], bf["xs"], bf["ys"], bf["zs"], bf["ms"], 64, 0.5, 0.05, 1.0, 5.0)
+    dx, dy, dz, lld = O.traverse_dp(bd["tree"], bd["com"], bd["xs"], bd["ys"], bd["zs"], bd["ms"], 64, 0.5, 0.05, 1.0, 5.0)
+    assert dx.dtype == np.float64
+    mean, mx = O.acc_error(ax, ay, az, dx, dy, dz)
+    assert mx < 1e-4                      # float rounding (and the rare borderline MAC decision)
+    assert abs(int(ll.sum()) - int(lld.sum())) <= 0.001 * ll.sum()
+    # theta = 0 in double is the direct sum in double, to summation order
+    d0 = O.traverse_dp(bd["tree"], bd["com"], bd["xs"], bd["ys"], bd["zs"], bd["ms"], 32, 0.0, 0.05, 1.0, 5.0)
+    ref = O.direct_dp(bd["xs"], bd["ys"], bd["zs"], bd["ms"], 0.05, 1.0)
+    assert np.all(d0[3] == n)
+    for a, r in zip(d0[:3], ref):
+        assert np.max(np.abs(a - r)) < 1e-12 * np.max(np.abs(r))
+
+
+def test_dp_sim_two_body_orbit_and_float_sim_closeness():
+    # circular two-body orbit, double: separation and energy stay put over 200 steps
+    x = np.array([2.0, 3.0]); y = np.array([2.5, 2.5]); z = np.array([2.5, 2.5])
+    m = np.array([1.0, 1.0])
+    eps = 1e-3
+    v = np.sqrt(1.0 / (2.0 * (1.0 + eps * eps) ** 1.5))   # G m r / (r^2+eps^2)^1.5 = v^2 / (r/2), r = 1
+    vy = np.array([-v, v])
+    sim = O.OracleSimDP(x, y, z, m, np.zeros(2), vy, np.zeros(2), bits=21, max_codes=32, group=32,
+                        theta=0.5, dt=1e-3, eps=eps)
+    sim.step()   # the first kick uses a = 0 (no forces at spawn), as in the reference
+    for _ in range(200):
+        sim.step()
+    s = sim.state()
+    r = np.sqrt((s["x"][0] - s["x"][1]) ** 2 + (s["y"][0] - s["y"][1]) ** 2)
+    assert s["x"].dtype == np.float64 and abs(r - 1.0) < 2e-3
+    # the float and double simulations of the same float-representable input stay close
+    import nbody_amd as nb
+    ic = nb.sample_ic(nb.IC_SPHERE, 2048, 2)
+    a = O.OracleSim(ic["x"], ic["y"], ic["z"], ic["m"] / 2048, bits=10, group=64, theta=0.5, dt=1e-3, eps=0.05)
+    b = O.OracleSimDP(ic["x"], ic["y"], ic["z"], ic["m"] / 2048, bits=10, group=64, theta=0.5, dt=1e-3, eps=0.05)
+    for _ in range(3):
+        a.step(); b.step()
+    sa, sb = a.state(), b.state()
+    assert a.counts()[:3] == b.counts()[:3]
+    assert np.array_equal(sa["id"], sb["id"])
+    assert np.max(np.abs(sa["x"] - sb["x"])) < 1e-5
