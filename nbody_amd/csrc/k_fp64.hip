@@ -292,10 +292,18 @@ __global__ __launch_bounds__(64 * T64_WAVES) void k64_traverse(
             fz = fma(dz, inv, fz);
         }
     };
-    auto flush = [&](int k) {   // every lane evaluates the ring's first k entries
+    // Every lane evaluates the ring's first k entries.  head only ever advances by 64 (the
+    // one shorter flush ends the kernel), so it is 0 or 64 and the k <= 64 entries are
+    // contiguous: the loop reads LDS at constant offsets from one base.
+    auto flush = [&](int k) {
         __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-        for (int j = 0; j < k; ++j) force(L.ring[(head + j) & (T64_RING - 1)]);
+        const Double4 *r = &L.ring[head];
+        if (k == 64) {
+#pragma unroll 8
+            for (int j = 0; j < 64; ++j) force(r[j]);
+        } else {
+            for (int j = 0; j < k; ++j) force(r[j]);
+        }
         head = (head + k) & (T64_RING - 1);
         cnt -= k;
         __builtin_amdgcn_wave_barrier();
