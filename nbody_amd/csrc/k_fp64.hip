@@ -236,6 +236,7 @@ __device__ __forceinline__ double rsq64(double t)
 // The decisions use the operation sequence of the host checker, so each group's source
 // list is identical to it.  Accepted monopoles and leaf particles go through an LDS ring
 // that every lane reads back (broadcast) 64 sources at a time.
+// A massless ring entry contributes exactly 0 (softening > 0 is enforced at create time).
 // Stack discipline: a round pops only as many nodes as can push 8 children each without
 // passing capacity - reserve; when not even one fits the round pops one node and may use
 // the reserve, which makes those rounds depth-first: the entries above the mark are then
@@ -269,8 +270,12 @@ __global__ __launch_bounds__(64 * T64_WAVES) void k64_traverse(
     T64Lds &L = lds[w];
     const int b0 = g * G;
     const int nb = min(G, n - b0);
-    const bool active = lane < nb;
-    const Double4 me = posm[active ? b0 + lane : b0];
+    // G = 32: the wave holds the group twice; each half evaluates every other source of the
+    // ring and the two partial sums are added at the end
+    const int bl = G == 32 ? (lane & 31) : lane;
+    const int half = G == 32 ? (lane >> 5) : 0;
+    const bool active = bl < nb;
+    const Double4 me = posm[active ? b0 + bl : b0];
     L.bx[lane] = me.x; L.by[lane] = me.y; L.bz[lane] = me.z;
     if (lane == 0) L.stack[0] = 0;
     int sp = 1;
@@ -297,8 +302,17 @@ __global__ __launch_bounds__(64 * T64_WAVES) void k64_traverse(
     // contiguous: the loop reads LDS at constant offsets from one base.
     auto flush = [&](int k) {
         __builtin_amdgcn_wave_barrier();
-        const Double4 *r = &L.ring[head];
-        if (k == 64) {
+        Double4 *r = &L.ring[head];
+        if constexpr (G == 32) {
+            if (k == 64) {
+#pragma unroll 8
+                for (int j = 0; j < 32; ++j) force(r[2 * j + half]);
+            } else {   // the last, shorter flush: a massless entry evens out an odd count
+                if ((k & 1) && lane == 0) r[k] = Double4{0.0, 0.0, 0.0, 0.0};
+                __builtin_amdgcn_wave_barrier();
+                for (int j = 0; j < (k + 1) / 2; ++j) force(r[2 * j + half]);
+            }
+        } else if (k == 64) {
 #pragma unroll 8
             for (int j = 0; j < 64; ++j) force(r[j]);
         } else {
@@ -382,9 +396,13 @@ __global__ __launch_bounds__(64 * T64_WAVES) void k64_traverse(
         __builtin_amdgcn_wave_barrier();
     }
     if (cnt > 0) flush(cnt);
+    if constexpr (G == 32) {
+        fx += __shfl_xor(fx, 32, 64); fy += __shfl_xor(fy, 32, 64); fz += __shfl_xor(fz, 32, 64);
+        ps += __shfl_xor(ps, 32, 64);
+    }
 
-    if (active) {
-        const int b = b0 + lane;
+    if (active && half == 0) {
+        const int b = b0 + bl;
         if (POT) {
             pot[b] = ps - me.w * rsq64(eps2);   // the body's own term, met exactly once
         } else {

@@ -140,10 +140,11 @@ def test_fp64_direct_sum_and_tree_accuracy():
     assert rel_err(dd, ref32) < 1e-13
 
 
-def test_fp64_theta_zero_is_the_direct_sum():
-    n = 3000
+@pytest.mark.parametrize("group,n", [(64, 3000), (32, 3000), (32, 2967)])
+def test_fp64_theta_zero_is_the_direct_sum(group, n):
     ic = make_ic64("sphere", n)
-    with new_sim64(n, morton_bits=21, theta=0.0, dt=0.0, softening_factor=0.05) as sim:
+    with new_sim64(n, morton_bits=21, theta=0.0, dt=0.0, softening_factor=0.05,
+                   traversal_group_size=group) as sim:
         sim.set_state(ic["x"], ic["y"], ic["z"], ic["m"])
         sim.update()
         st = sim.get_state()
