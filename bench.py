@@ -116,6 +116,18 @@ def run_direct(args, world, rank, local_rank):
         K = max(args.steps, 1)
         rate = float(n) * n * K / elapsed
         tf = 20 * rate / 1e12
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            # the oracle's float32 direct sum on 131,072 target bodies against all 1,048,576 sources
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O
+            nt = 131072
+            tc = time.perf_counter()
+            O.direct_f32(posm[:, 0], posm[:, 1], posm[:, 2], posm[:, 3], eps, grav, 0, nt)
+            tc = time.perf_counter() - tc
+            cpu = {"value": round(nt * float(n) / tc), "unit": "interactions/s",
+                   "cores": O.lib().orc_num_threads(), "kind": "port",
+                   "sample": f"{nt} target bodies x {n} sources ({tc:.1f} s), OpenMP over targets"}
         print(json.dumps({
             "metric": "interactions/s, O(N^2) direct sum", "value": round(rate), "unit": "interactions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -126,7 +138,8 @@ def run_direct(args, world, rank, local_rank):
             "finite": finite,
             "roofline": {"bound": "valu", "kernel": "k_direct", "achieved": round(tf, 2),
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_TFLOPS, 4),
-                         "traffic": None, "note": "20 FLOP x N^2 / wall time incl. ring exchange"}}))
+                         "traffic": None, "note": "20 FLOP x N^2 / wall time incl. ring exchange"},
+            "cpu_baseline": cpu}))
     dist.barrier()
     dist.destroy_process_group()
 
