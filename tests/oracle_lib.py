@@ -372,8 +372,6 @@ class OracleSimDP:
             out[k] = np.empty(no, np.int32)
         for k in ("comx", "comy", "comz", "mass"):
             out[k] = np.empty(no, np.float64)
-        ng = 0
-        out["list_len"] = None
         lib().orc_sim_get_tree_dp(self._h, _p(out["codes_sorted"]), _p(out["first_child"]),
                                   _p(out["num_children"]), _p(out["points_begin"]),
                                   _p(out["points_end"]), _p(out["comx"]), _p(out["comy"]),
