@@ -261,7 +261,7 @@ __global__ __launch_bounds__(64 * T64_WAVES) void k64_traverse(
     int n, int ngroups, const Double4 *__restrict__ posm, const Double4 *__restrict__ nodeA,
     const NodeB *__restrict__ nodeB, double theta2, double eps2, double gravity, double dinit,
     double *__restrict__ ax, double *__restrict__ ay, double *__restrict__ az,
-    double *__restrict__ pot, uint32_t *__restrict__ list_len, uint32_t *err)
+    double *__restrict__ pot, uint32_t *__restrict__ list_len, uint32_t *err, int stack_cap)
 {
     __shared__ T64Lds lds[T64_WAVES];
     const int lane = (int) threadIdx.x & 63, w = (int) threadIdx.x >> 6;
@@ -332,11 +332,11 @@ __global__ __launch_bounds__(64 * T64_WAVES) void k64_traverse(
 
     int rounds = 0;
     while (sp > 0) {
-        if (++rounds > (1 << 22) || sp > T64_STACK - 8) {   // cannot happen: see the discipline above
+        if (++rounds > (1 << 22) || sp > stack_cap - 8) {   // cannot happen: see the discipline above
             if (lane == 0) atomicOr(err, DEV_ERR_STACK);
             break;
         }
-        const int fit = (T64_STACK - T64_RESERVE - sp) / 7;
+        const int fit = (stack_cap - T64_RESERVE - sp) / 7;
         const int p = fit >= 1 ? min(min(64, sp), fit) : 1;
         const int node = lane < p ? L.stack[sp - p + lane] : -1;
         sp -= p;
@@ -560,11 +560,13 @@ hipError_t launch64_traverse(Sim *s, bool potential)
     const int grid = (ngroups + T64_WAVES - 1) / T64_WAVES;
     const double theta = (double) s->p.theta, eps = (double) s->p.softening_factor;
     const double dom = (double) s->p.domain_size;
+    // test aid: 32 usable entries make single-node depth-first rounds the common case
+    const int stack_cap = (s->p.flags & NBODY_FLAG_DEBUG_SMALL_STACK) ? T64_RESERVE + 32 : T64_STACK;
 #define NB_T64(GG, PP)                                                                           \
     hipLaunchKernelGGL((k64_traverse<GG, PP>), dim3(grid), dim3(64 * T64_WAVES), 0, s->stream,    \
                        s->n, ngroups, d.posm, d.nodeA, s->nodeB, theta * theta, eps * eps,        \
                        (double) s->p.gravity, dom * dom * 3.0, d.ax, d.ay, d.az, d.pot,           \
-                       s->list_len, &s->counts->err)
+                       s->list_len, &s->counts->err, stack_cap)
     if (s->group == 64) { if (potential) NB_T64(64, true); else NB_T64(64, false); }
     else                { if (potential) NB_T64(32, true); else NB_T64(32, false); }
 #undef NB_T64

@@ -267,3 +267,21 @@ def test_fp64_spawn_and_small_cases():
             assert st["ax"][0] == 0.0
         else:
             assert rel_err((st["ax"], st["ay"], st["az"]), d) < 1e-12
+
+
+@pytest.mark.parametrize("group", [64, 32])
+def test_fp64_tiny_stack_gives_the_same_lists(group):
+    """NBODY_FLAG_DEBUG_SMALL_STACK: 32 usable stack entries force the depth-first single-node
+    rounds; source lists are unchanged, sums differ only by their order."""
+    n = 60000
+    ic = make_ic64("clusters", n, seed=17)
+    res = []
+    for flags in (0, nb.FLAG_DEBUG_SMALL_STACK):
+        with new_sim64(n, morton_bits=21, theta=0.5, dt=0.0, traversal_group_size=group, flags=flags) as sim:
+            sim.set_state(ic["x"], ic["y"], ic["z"], ic["m"])
+            sim.update()
+            sim.sync()
+            res.append((sim.get_octree()["list_len"], sim.get_state()))
+    assert np.array_equal(res[0][0], res[1][0])
+    a, b = res[0][1], res[1][1]
+    assert rel_err((a["ax"], a["ay"], a["az"]), (b["ax"], b["ay"], b["az"])) < 1e-12
