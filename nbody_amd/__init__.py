@@ -368,6 +368,16 @@ class Simulation:
         out["U"], out["M"], out["n_oct"] = U, M, no
         return out
 
+    def get_list_len(self) -> np.ndarray:
+        """Per group: number of sources of the last traversal (nbody_octree_view.list_len only)."""
+        n = self.count()
+        g = self.params.traversal_group_size
+        out = np.empty((n + g - 1) // g, np.uint32)
+        view = COctreeView()
+        view.list_len = out.ctypes.data
+        self._check(self._lib.nbody_get_octree(self._h, C.byref(view)))
+        return out
+
     def get_timings(self) -> dict:
         t = CTimings()
         self._check(self._lib.nbody_get_timings(self._h, C.byref(t)))

@@ -178,9 +178,13 @@ class OracleLetBackend:
 
     def begin_local_forces(self):
         b = self.tree
-        ax, ay, az, _ = O.traverse(b["tree"], b["com"], self.x, self.y, self.z, self.m, self.group,
-                                   self.theta, self.eps, 1.0, 5.0)
+        ax, ay, az, ll = O.traverse(b["tree"], b["com"], self.x, self.y, self.z, self.m, self.group,
+                                    self.theta, self.eps, 1.0, 5.0)
         self.acc = [ax, ay, az]
+        self.work = ll.astype(np.float64)
+
+    def work_weights(self):
+        return np.repeat(self.work, self.group)[:len(self.x)]
 
     def bbox(self):
         return np.array([self.x.min(), self.y.min(), self.z.min(),
@@ -196,10 +200,11 @@ class OracleLetBackend:
         if len(r) == 0:
             return
         b = O.full_build(r[:, 0], r[:, 1], r[:, 2], r[:, 3], 5.0, self.bits, 32)
-        ax, ay, az, _ = O.traverse_from((self.x, self.y, self.z), b["tree"], b["com"], b["xs"],
-                                        b["ys"], b["zs"], b["ms"], self.group, self.theta,
-                                        self.eps, 1.0, 5.0, acc=self.acc)
+        ax, ay, az, ll = O.traverse_from((self.x, self.y, self.z), b["tree"], b["com"], b["xs"],
+                                         b["ys"], b["zs"], b["ms"], self.group, self.theta,
+                                         self.eps, 1.0, 5.0, acc=self.acc)
         self.acc = [ax, ay, az]
+        self.work = self.work + ll
 
     def finish_step(self):
         self.v = [(np.float32(0.5) * a * np.float32(self.dt) + h).astype(np.float32)
@@ -227,10 +232,11 @@ def _let_worker(rank, world, port, n, q, rebalance_at=-1):
     moved = 0
     for i in range(3):
         if i == rebalance_at:
-            moved = st.rebalance(sample=512, seed=i)
+            moved = st.rebalance(sample=512, seed=i, weighted=True)
         st.step()
         sent.append((st.last_sent, st.last_received))
-    q.put((rank, be.gid, be.x, be.y, be.v[0], be.acc[0], be.acc[1], be.acc[2], sent, moved))
+    q.put((rank, be.gid, be.x, be.y, be.v[0], be.acc[0], be.acc[1], be.acc[2], sent, moved,
+           float(be.work_weights().sum())))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -254,7 +260,7 @@ def test_let_stepper_tracks_single_rank_and_direct_sum(world, n, rebalance_at):
         assert p.exitcode == 0
     ic = _ic(n)
     x, y, vx, ax, ay, az = (np.full(n, np.nan, np.float32) for _ in range(6))
-    for rank, gid, rx, ry, rvx, rax, ray, raz, sent, moved in res:
+    for rank, gid, rx, ry, rvx, rax, ray, raz, sent, moved, work in res:
         x[gid], y[gid], vx[gid], ax[gid], ay[gid], az[gid] = rx, ry, rvx, rax, ray, raz
         # a surface term: every step something is exchanged, far fewer records than particles
         assert all(0 < s < n and 0 < r < n for s, r in sent)
@@ -263,7 +269,10 @@ def test_let_stepper_tracks_single_rank_and_direct_sum(world, n, rebalance_at):
     if rebalance_at >= 0:
         # the disk has moved for two steps: the fresh bisection differs from the initial one
         assert sum(r[9] for r in res) > 0
-        assert max(len(r[1]) for r in res) - min(len(r[1]) for r in res) < 0.2 * n / world
+        # the new cuts equalise work (body-source interactions of the last force evaluation),
+        # not particle counts
+        works = np.array([r[10] for r in res])
+        assert works.max() < 1.25 * works.mean(), works
     ref = OracleBackend(ic, n, 64, 0.5, 1e-3, 0.01, 21)
     for _ in range(3):
         ref.update()
@@ -284,3 +293,23 @@ def test_let_stepper_tracks_single_rank_and_direct_sum(world, n, rebalance_at):
     d = O.direct_f64(x, y, zz, ic["m"], 0.01, 1.0)
     mean, mx = O.acc_error(ax, ay, az, *d)
     assert mean < 2e-3, mean
+
+
+def test_orb_cuts_follow_the_weights():
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(0, 1, (20000, 3)) * np.array([4.0, 1.0, 1.0])      # longest axis: x
+    # unweighted: equal counts, as domain_slices cuts them
+    c = parallel.orb_cuts(pts, 4)
+    cnt = np.bincount(parallel.orb_assign(c, pts), minlength=4)
+    assert cnt.max() - cnt.min() <= 4
+    # the right half of the box costs nine times as much per particle
+    w = np.where(pts[:, 0] > 2.0, 9.0, 1.0)
+    c = parallel.orb_cuts(pts, 4, w)
+    dom = parallel.orb_assign(c, pts)
+    work = np.bincount(dom, weights=w, minlength=4)
+    assert work.max() < 1.02 * work.mean()
+    assert np.bincount(dom, minlength=4).max() > 2 * np.bincount(dom, minlength=4).min()
+    # three parts: 1/3 of the weight left of the first cut
+    c3 = parallel.orb_cuts(pts, 3, w)
+    work3 = np.bincount(parallel.orb_assign(c3, pts), weights=w, minlength=3)
+    assert work3.max() < 1.02 * work3.mean()

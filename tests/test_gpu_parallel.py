@@ -123,6 +123,11 @@ sim = nb.Simulation(nb.Params(num_points=cap, morton_bits=21, theta=0.6, dt=1e-3
 sim.set_particles(ic["x"][idx], ic["y"][idx], ic["z"][idx], ic["m"][idx], id=idx.astype(np.uint32))
 st = parallel.LetStepper(parallel.GpuLetBackend(sim, "cuda:0", exchange_device="cpu"))
 st.step()
+a0 = sim.get_state()
+w = st.b.work_weights()          # re-runs both traversals: accelerations must come out the same
+a1 = sim.get_state()
+assert len(w) == len(a0["x"]) and w.min() > 0
+assert all(np.array_equal(a0[k], a1[k]) for k in ("ax", "ay", "az", "x", "vx"))
 moved = st.rebalance(sample=1024, seed=1)
 st.step()
 s = sim.get_state()
