@@ -54,7 +54,7 @@ void free_all(Sim *s)
     F(s->rt_level); F(s->rt_lb); F(s->rt_le); F(s->rt_left); F(s->rt_right); F(s->depth_key);
     F(s->bfs); F(s->octid); F(s->o_depth); F(s->o_first_child); F(s->o_num_children); F(s->o_lb);
     F(s->o_le); F(s->o_level); F(s->o_pb); F(s->o_pe); F(s->o_parent); F(s->o_size); F(s->o_wsum);
-    F(s->nodeA); F(s->nodeB); F(s->list_len); F(s->inter_dev); F(s->trav_tail); F(s->pot);
+    F(s->nodeA); F(s->nodeB); F(s->list_len); F(s->inter_dev); F(s->trav_tail); F(s->trav_heavy_ctrl); F(s->pot);
     F(s->tw_posm); F(s->tw_pot); F(s->ds_pot); F(s->let_boxes); F(s->let_counts);
     for (int k = 0; k < 3; ++k) { F(s->tw_v[k]); F(s->tw_vh[k]); F(s->tw_a[k]); F(s->ds_a[k]); }
     State64 &d = s->d;
@@ -165,6 +165,18 @@ int alloc_all(Sim *s)
             t.vhx[i] = s->vhx[i]; t.vhy[i] = s->vhy[i]; t.vhz[i] = s->vhz[i];
             t.vx[i] = s->vx[i]; t.vy[i] = s->vy[i]; t.vz[i] = s->vz[i];
         }
+        const size_t gcap = (n + 31) / 32;   // groups at the smaller group size
+        const size_t hw = 8 + TRAV_HEAVY_MAX + 3 * gcap;
+        NB_HIP(s, dalloc(&s->trav_heavy_ctrl, hw));
+        NB_HIP(s, hipMemsetAsync(s->trav_heavy_ctrl, 0, hw * sizeof(uint32_t), s->stream));
+        s->trav_heavy_list = s->trav_heavy_ctrl + 8;
+        s->trav_heavy_flag = s->trav_heavy_list + TRAV_HEAVY_MAX;
+        s->trav_cost[0] = s->trav_heavy_flag + gcap;
+        s->trav_cost[1] = s->trav_cost[0] + gcap;
+        t.cost[0] = s->trav_cost[0]; t.cost[1] = s->trav_cost[1];
+        t.heavy_ctrl = s->trav_heavy_ctrl;
+        t.heavy_list = s->trav_heavy_list;
+        t.heavy_flag = s->trav_heavy_flag;
         NB_HIP(s, dalloc(&s->trav_tail, 1));
         NB_HIP(s, hipMemcpy(s->trav_tail, &t, sizeof t, hipMemcpyHostToDevice));
     }

@@ -31,6 +31,9 @@
 // The set of sources a group interacts with does not depend on the order candidates are
 // visited in, so list lengths equal those of the reference's breadth-first walk.
 #include <cstdio>
+#include <cstdlib>
+#include <vector>
+
 #include "dev_utils.hpp"
 #include "nbody_internal.hpp"
 
@@ -48,6 +51,9 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 #endif
 #if NB_WALK_PROFILE
 __device__ unsigned long long g_walk_prof[8];
+// per group: wall-clock begin and end (100 MHz ticks) and the hardware id of its wave; the
+// launcher writes them to the file named by NB_WALK_TRACE (scratch/trace_an.py reads it)
+__device__ unsigned long long g_walk_trace[3 * 65536];
 #define PROF_T0() const long long t0_ = clock64()
 #define PROF_ADD(slot) do { if (lane == 0) prof_acc[slot] += clock64() - t0_; } while (0)
 #else
@@ -80,14 +86,25 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
     const v8f *__restrict__ posm2, const Float4 *__restrict__ nodeA,
     const NodeB *__restrict__ nodeB, float theta, float eps2, float gravity, float domain,
     float dt, float keep, const TravTail *__restrict__ tail, int cur, int accumulate,
-    int stack_limit)
+    int stack_limit, int kind, int sum_slot)
 {
     __shared__ WaveLds lds[TRAV_WAVES];
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int lblk = xcd_remap((int) blockIdx.x, (int) gridDim.x);
-    const int g = g0 + lblk * TRAV_WAVES + w;
-    if (g >= g1) return;
+    // Launch order (see k_mark_heavy): the first TRAV_HEAVY_MAX wave slots take the groups
+    // marked heavy, one each; the other slots take all groups in Morton order, consecutive
+    // ones on the same XCD, and skip the marked ones.
+    int g;
+    constexpr int HB = TRAV_HEAVY_MAX / TRAV_WAVES;
+    if ((int) blockIdx.x < HB) {
+        const int slot = (int) blockIdx.x * TRAV_WAVES + w;
+        if (slot >= (int) min(tail->heavy_ctrl[4 * kind + 1], (uint32_t) TRAV_HEAVY_MAX)) return;
+        g = g0 + (int) tail->heavy_list[slot];
+    } else {
+        const int lblk = xcd_remap((int) blockIdx.x - HB, (int) gridDim.x - HB);
+        g = g0 + lblk * TRAV_WAVES + w;
+        if (g >= g1 || tail->heavy_flag[g - g0]) return;
+    }
     WaveLds &L = lds[w];
     float *bxyf = reinterpret_cast<float *>(L.bxy);
     float *bzf = reinterpret_cast<float *>(L.bz);
@@ -524,8 +541,17 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
         prof_acc[3] = clock64() - t_begin;
         prof_acc[5] = wall_clock64() - r_begin;
         for (int i = 0; i < 6; ++i) atomicAdd(&g_walk_prof[i], (unsigned long long) prof_acc[i]);
+        if (g < 65536) {
+            g_walk_trace[3 * g] = (unsigned long long) r_begin;
+            g_walk_trace[3 * g + 1] = (unsigned long long) wall_clock64();
+            g_walk_trace[3 * g + 2] = (unsigned long long) __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+        }
     }
 #endif
+    if (lane == 0) {   // what the next launch against this kind of tree orders its groups by
+        tail->cost[kind][g] = total;
+        atomicAdd(&tail->heavy_ctrl[4 * kind + sum_slot], total >> 4);
+    }
     if (MODE == TRAV_POTENTIAL) {
         if (active) {
             float p = fx;
@@ -545,6 +571,34 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
             tail->vz[cur][b] = fmaf(0.5f * azv, dt, tail->vhz[cur][b]) * keep;
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// Heavy groups go first.  A group whose 64 Morton-consecutive bodies straddle a large cell
+// boundary is spread out in space, opens almost every node and has a source list several
+// times the mean; a domain of a decomposition whose cut plane lies just beside such a
+// boundary has a whole run of them at one end of its Morton order.  Started last, they
+// finish alone long after every other wave has gone (measured: +0.8 ms on a 4 ms kernel).
+// cost[i] = list length of group g0 + i in the previous launch against the same kind of
+// tree, sum16 = the sum of those lengths / 16 over that launch's prev_groups groups.  Groups
+// above twice the mean (at most TRAV_HEAVY_MAX of them) are listed and flagged; the traversal
+// starts the listed ones first and skips them in the Morton-ordered part of its grid.
+// heavy_n is zeroed by the launcher.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mark_heavy(const uint32_t *__restrict__ cost, int ngroups,
+                                                    const uint32_t *__restrict__ sum16, int prev_groups,
+                                                    uint32_t *heavy_n, uint32_t *__restrict__ heavy_list,
+                                                    uint32_t *__restrict__ heavy_flag)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ngroups) return;
+    const unsigned long long thr = prev_groups > 0 ? 32ull * *sum16 / (unsigned long long) prev_groups : ~0ull;
+    uint32_t flag = 0;
+    if (thr > 0 && (unsigned long long) cost[i] > thr) {
+        const uint32_t k = atomicAdd(heavy_n, 1u);
+        if (k < (uint32_t) TRAV_HEAVY_MAX) { heavy_list[k] = (uint32_t) i; flag = 1; }
+    }
+    heavy_flag[i] = flag;
 }
 
 // *out (u64, zeroed by the launcher) += sum over groups of list_len[g] * bodies_in_group(g).
@@ -655,14 +709,26 @@ static hipError_t traverse_impl(Sim *s, Sim *src, bool fuse_vel, int acc_flag, b
     const int g1 = s->trav_g1 < 0 ? ngroups : std::min(s->trav_g1, ngroups);
     const int c = s->cur;
     if (g1 > g0) {
-        const int grid = (g1 - g0 + TRAV_WAVES - 1) / TRAV_WAVES;
+        const int grid = (g1 - g0 + TRAV_WAVES - 1) / TRAV_WAVES + TRAV_HEAVY_MAX / TRAV_WAVES;
+        // heavy_ctrl[4 * kind] = {sum A, heavy_n, sum B}: this launch reads the sum the previous
+        // launch of the same kind accumulated and accumulates into the other one
+        const int kind = src == s ? 0 : 1;
+        const int rd = s->trav_sum_slot[kind], wr = 2 - rd;
+        uint32_t *ctrl = s->trav_heavy_ctrl + 4 * kind;
+        hipError_t me = hipMemsetAsync(ctrl + std::min(1, wr), 0, 2 * sizeof(uint32_t), s->stream);
+        if (me != hipSuccess) return me;
+        hipLaunchKernelGGL(k_mark_heavy, dim3((g1 - g0 + 255) / 256), dim3(256), 0, s->stream,
+                           s->trav_cost[kind] + g0, g1 - g0, ctrl + rd, s->trav_prev_groups[kind],
+                           ctrl + 1, s->trav_heavy_list, s->trav_heavy_flag);
+        s->trav_sum_slot[kind] = wr;
+        s->trav_prev_groups[kind] = g1 - g0;
         const float eps2 = s->p.softening_factor * s->p.softening_factor;
         const float keep = 1.0f - s->p.velocity_dampening;
 #define NB_TRAV(GG, FV, WO)                                                                      \
     hipLaunchKernelGGL((k_traverse<GG, FV, (WO)>), dim3(grid), dim3(64 * TRAV_WAVES), 0, s->stream,    \
                        s->n, g0, g1, s->posm, src->posm, (const v8f *) src->posm2, src->nodeA,       \
                        src->nodeB, s->p.theta, eps2, s->p.gravity, s->p.domain_size, s->p.dt, keep,  \
-                       s->trav_tail, c, acc_flag, stack_limit)
+                       s->trav_tail, c, acc_flag, stack_limit, kind, wr)
         const bool walk_only = (s->p.flags & NBODY_FLAG_DEBUG_WALK_ONLY) != 0;
         // test aid: a node stack with 32 usable entries makes unexpanded push-backs and
         // depth-first single-node rounds the common case
@@ -682,6 +748,11 @@ static hipError_t traverse_impl(Sim *s, Sim *src, bool fuse_vel, int acc_flag, b
         unsigned long long h[8], z[8] = {0};
         (void) hipMemcpyFromSymbol(h, HIP_SYMBOL(g_walk_prof), sizeof h);
         (void) hipMemcpyToSymbol(HIP_SYMBOL(g_walk_prof), z, sizeof z);
+        if (const char *path = getenv("NB_WALK_TRACE")) {
+            std::vector<unsigned long long> tr(3 * 65536);
+            (void) hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(g_walk_trace), tr.size() * 8);
+            if (FILE *f = fopen(path, "wb")) { fwrite(tr.data(), 8, 3 * (size_t) std::min(g1 - g0, 65536), f); fclose(f); }
+        }
         const double tot = (double) h[3];
         fprintf(stderr, "walk profile: groups %d  MAC rounds/group %.1f  wave-cycles/group %.0f | "
                         "MAC+push %.1f%%  leaf runs (scalar path) %.1f%%  ring flush %.1f%%  other %.1f%%  "

@@ -23,6 +23,7 @@ constexpr int LET_MAX_BOXES = 256;
 constexpr int TRAV_WAVES = 4;                       // groups (waves) per traversal workgroup
 constexpr int TRAV_STACK = 512;                     // LDS inner-node stack entries per wave
 constexpr int TRAV_LEAF_STACK = 544;                // LDS leaf stack entries per wave
+constexpr int TRAV_HEAVY_MAX = 1024;                // groups the traversal can start ahead of the rest
 constexpr int TRAV_PEND = 96;                       // LDS queue of candidates awaiting the exact test
 constexpr int MAX_DEPTH_BINS = 256;                 // depth key space of the node ranking pass
 constexpr int TIMING_RING = 64;
@@ -47,6 +48,11 @@ struct TravTail {
     float *vhx[2], *vhy[2], *vhz[2];
     float *vx[2], *vy[2], *vz[2];
     float *pot;
+    // launch order of the traversal (k_mark_heavy)
+    uint32_t *cost[2];            // per group: list length in the last launch against the own / another tree
+    uint32_t *heavy_ctrl;         // [2][4]: per kind {sum A, heavy_n, sum B, -}
+    const uint32_t *heavy_list;   // [TRAV_HEAVY_MAX] groups (relative to the launch's first) to start first
+    const uint32_t *heavy_flag;   // [groups] 1 = listed
 };
 
 // Device-resident counters written by the build kernels (one int each).
@@ -146,6 +152,9 @@ struct Sim {
     NodeB *nodeB = nullptr;
     uint32_t *list_len = nullptr; // [ceil(n/group)]
     TravTail *trav_tail = nullptr;
+    uint32_t *trav_heavy_ctrl = nullptr, *trav_heavy_list = nullptr, *trav_heavy_flag = nullptr;
+    uint32_t *trav_cost[2]{};
+    int trav_sum_slot[2] = {0, 0}, trav_prev_groups[2] = {0, 0};
     float *pot = nullptr;            // per-body potential sums (allocated by the first energy call)
     // LET exchange scratch
     float *let_boxes = nullptr;      // [64][6] device copy of the remote boxes

@@ -432,3 +432,38 @@ def test_group_of_32_ragged_sizes(n, bits, theta):
     err = np.sqrt((st["ax"] - ax) ** 2 + (st["ay"] - ay) ** 2 + (st["az"] - az) ** 2)
     ref_n = np.sqrt(ax.astype(np.float64) ** 2 + ay ** 2 + az ** 2)
     assert (err / np.maximum(ref_n, 1e-30)).max() < 1e-4
+
+
+@pytest.mark.parametrize("group", [64, 32])
+def test_heavy_groups_are_started_first_and_done_once(group):
+    """A thin slab of bodies across a large cell boundary (x = 2.5) sits at the end of the Morton
+    order in groups that are spread out in space: their source lists are several times the
+    mean.  From the second launch on the traversal starts such groups ahead of the others; every
+    group must still be done exactly once, with the same list and the same forces."""
+    rng = np.random.default_rng(11)
+    n = 300000
+    p = rng.uniform(2.0, 2.5, (n, 3)).astype(np.float32)
+    k = 400
+    p[:k, 0] = rng.uniform(2.5, 2.5001, k).astype(np.float32)      # the slab
+    m = rng.uniform(0.5, 1.5, n).astype(np.float32)
+    eps, theta = 0.01, 1.0
+    with new_sim(n, morton_bits=21, traversal_group_size=group, theta=theta, dt=0.0,
+                 softening_factor=eps) as sim:
+        sim.set_state(p[:, 0], p[:, 1], p[:, 2], m)
+        lists, accs = [], []
+        for _ in range(3):            # dt = 0: the same forces three times, ordered differently
+            sim.update()
+            st = sim.get_state()
+            lists.append(sim.get_list_len())
+            accs.append(np.stack([st["ax"], st["ay"], st["az"]]))
+    ref = O.full_build(p[:, 0], p[:, 1], p[:, 2], m, 5.0, 21, 32)
+    ax, ay, az, ll = O.traverse(ref["tree"], ref["com"], ref["xs"], ref["ys"], ref["zs"], ref["ms"],
+                                group, theta, eps, 1.0, 5.0)
+    assert ll.max() > 2.2 * ll.mean()             # above the traversal's "twice the mean" mark
+    for got in lists:
+        assert np.array_equal(got, ll)
+    assert np.array_equal(accs[0], accs[1]) and np.array_equal(accs[1], accs[2])
+    err = np.sqrt(((accs[2] - np.stack([ax, ay, az])) ** 2).sum(0))
+    # float32 sums of ~10^4 terms in a different order (bodies inside a uniform cube: the terms
+    # largely cancel)
+    assert (err / np.sqrt(ax.astype(np.float64) ** 2 + ay ** 2 + az ** 2)).max() < 2e-4
