@@ -467,3 +467,48 @@ def test_heavy_groups_are_started_first_and_done_once(group):
     # float32 sums of ~10^4 terms in a different order (bodies inside a uniform cube: the terms
     # largely cancel)
     assert (err / np.sqrt(ax.astype(np.float64) ** 2 + ay ** 2 + az ** 2)).max() < 2e-4
+
+
+def test_largest_configuration_properties_and_sampled_accuracy():
+    """16,777,216-particle Plummer sphere (the largest single-GPU configuration), theta = 0.6,
+    63-bit keys: size-independent properties of the build, and the tree forces of 192 sampled
+    bodies against a float64 direct sum over all sources."""
+    n = 1 << 24
+    eps, theta = 1e-3, 0.6
+    ic = nb.sample_ic(nb.IC_PLUMMER, n, 42, p0=0.1, p1=1.0)
+    with new_sim(n, morton_bits=21, theta=theta, dt=0.0, softening_factor=eps) as sim:
+        sim.set_state(ic["x"], ic["y"], ic["z"], ic["m"])
+        sim.update()
+        sim.sync()                                   # reports device-side errors
+        g = sim.get_octree()
+        st = sim.get_state()
+    cs, perm = g["codes_sorted"], g["perm"]
+    assert np.all(cs[1:] >= cs[:-1])
+    assert np.array_equal(np.sort(st["id"]), np.arange(n, dtype=np.uint32))
+    assert np.array_equal(st["x"], ic["x"][st["id"]])                  # dt = 0: nothing moved
+    leaf = g["num_children"] == 0
+    cnt = g["points_end"] - g["points_begin"] + 1
+    assert cnt[leaf].sum() == n and cnt[0] == n
+    assert np.isclose(g["mass"][0], 1.0, rtol=1e-4)                    # total mass 1
+    inner = ~leaf
+    assert g["num_children"][inner].min() >= 2 and g["num_children"].max() <= 8
+    for k in ("ax", "ay", "az"):
+        assert np.isfinite(st[k]).all()
+    # momentum: sum m a = 0 up to the tree's asymmetry (monopoles are not pairwise symmetric)
+    f = np.array([(st["m"].astype(np.float64) * st[k]).sum() for k in ("ax", "ay", "az")])
+    scale = (st["m"].astype(np.float64) * np.sqrt(st["ax"].astype(np.float64) ** 2 + st["ay"] ** 2 + st["az"] ** 2)).sum()
+    assert np.linalg.norm(f) < 2e-3 * scale
+    # sampled accuracy
+    pick = np.random.default_rng(0).choice(n, 192, replace=False)
+    x, y, z, m = (st[k].astype(np.float64) for k in ("x", "y", "z", "m"))
+    e2 = float(np.float32(eps)) ** 2
+    err = []
+    for i in pick:
+        dx, dy, dz = x - x[i], y - y[i], z - z[i]
+        s = dx * dx + dy * dy + dz * dz + e2
+        w = m / (s * np.sqrt(s))
+        ref = np.array([(dx * w).sum(), (dy * w).sum(), (dz * w).sum()])
+        got = np.array([st["ax"][i], st["ay"][i], st["az"][i]], np.float64)
+        err.append(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+    err = np.array(err)
+    assert err.mean() < 2e-3 and err.max() < 3e-2, (err.mean(), err.max())
