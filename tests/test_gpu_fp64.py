@@ -285,3 +285,23 @@ def test_fp64_tiny_stack_gives_the_same_lists(group):
     assert np.array_equal(res[0][0], res[1][0])
     a, b = res[0][1], res[1][1]
     assert rel_err((a["ax"], a["ay"], a["az"]), (b["ax"], b["ay"], b["az"])) < 1e-12
+
+
+def test_fp64_headline_workload_lists_match_oracle():
+    """The headline workload (2,097,152-particle sphere, theta = 0.6, 63-bit keys) on a double
+    handle: every tree array, every group's list length, accelerations to 1e-12."""
+    n, theta, eps = 1 << 21, 0.6, 0.1
+    ic = make_ic64("sphere", n)
+    with new_sim64(n, morton_bits=21, theta=theta, dt=0.0, softening_factor=eps) as sim:
+        sim.set_state(ic["x"], ic["y"], ic["z"], ic["m"])
+        sim.update()
+        gpu = sim.get_octree()
+        st = sim.get_state()
+    ref = O.full_build_dp(ic["x"], ic["y"], ic["z"], ic["m"], 5.0, 21, 32)
+    assert np.array_equal(gpu["perm"], np.arange(n))
+    gpu["perm"] = ref["perm"]
+    assert_build_equal(gpu, ref, exact_com=True)
+    ax, ay, az, ll = O.traverse_dp(ref["tree"], ref["com"], ref["xs"], ref["ys"], ref["zs"], ref["ms"],
+                                   64, theta, eps, 1.0, 5.0)
+    assert np.array_equal(gpu["list_len"], ll)
+    assert rel_err((st["ax"], st["ay"], st["az"]), (ax, ay, az)) < 1e-12
