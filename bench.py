@@ -219,7 +219,7 @@ def main():
         ic = nb.sample_ic(nb.IC_SPHERE, n, 42)
     if let:
         from nbody_amd import parallel
-        own = parallel.domain_slices(ic["x"], ic["y"], ic["z"], world)[rank]
+        own = parallel.domain_slices(ic["x"], ic["y"], ic["z"], world, grid=(5.0, args.morton_bits))[rank]
         ic = {k: v[own] for k, v in ic.items()}
     else:
         assert ngroups % world == 0, "groups must divide evenly over the ranks"

@@ -9,7 +9,7 @@ world = int(sys.argv[1]); n_per = int(sys.argv[2]); kind = sys.argv[3] if len(sy
 n = world * n_per
 ic = nb.sample_ic(nb.IC_SPHERE, n, 42) if kind == "sphere" else nb.sample_ic(nb.IC_PLUMMER, n, 42, p0=0.1, p1=1.0)
 EPS = 0.1 if kind == "sphere" else 1e-3
-parts = parallel.domain_slices(ic["x"], ic["y"], ic["z"], world)
+parts = parallel.domain_slices(ic["x"], ic["y"], ic["z"], world, grid=(5.0, 21) if os.environ.get("NO_SNAP") != "1" else None)
 sims, bes = [None] * world, [None] * world
 alloc_order = range(world) if os.environ.get("ALLOC_REV") != "1" else range(world - 1, -1, -1)
 for r in alloc_order:

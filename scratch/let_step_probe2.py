@@ -21,14 +21,13 @@ for q in range(world):
     incs.append(b.let_export(box[None])[0].clone()); s.close()
 inc = torch.cat(incs)
 torch.cuda.synchronize()
-for flags, label in ((0, "side stream"), (nb.FLAG_NO_SIDE_STREAM, "one stream")):
+for flags, label in ((0, "two launches"), (0, "one launch")):
     s = mk(parts[r], flags); b = parallel.GpuLetBackend(s, "cuda:0")
     for it in range(5):
         b.update(); s.sync(); torch.cuda.synchronize(); t0 = time.perf_counter()
-        if os.environ.get("BUILD_FIRST") == "1" and it > 0:
+        if label == "one launch" and it > 0:
             b.remote.set_sources_dev(inc.data_ptr(), int(inc.shape[0]))
-            b.begin_local_forces()
-            s.traverse_from(b.remote, accumulate=True)
+            s.traverse_pair(b.remote)
             b.finish_step(); s.sync()
         else:
             b.begin_local_forces(); b.add_remote(inc); b.finish_step(); s.sync()

@@ -10,7 +10,7 @@ world, n_per = 8, 2097152
 kind = sys.argv[1] if len(sys.argv) > 1 else "sphere"
 ic = nb.sample_ic(nb.IC_SPHERE, world * n_per, 42) if kind == "sphere" else nb.sample_ic(nb.IC_PLUMMER, world * n_per, 42, p0=0.1, p1=1.0)
 EPS = 0.1 if kind == "sphere" else 1e-3
-parts = parallel.domain_slices(ic["x"], ic["y"], ic["z"], world)
+parts = parallel.domain_slices(ic["x"], ic["y"], ic["z"], world, grid=(5.0, 21) if os.environ.get("NO_SNAP") != "1" else None)
 for flags, label in ((0, "side stream"), (nb.FLAG_NO_SIDE_STREAM, "one stream")):
     sims, bes = [], []
     for idx in parts:

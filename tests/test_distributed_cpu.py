@@ -313,3 +313,37 @@ def test_orb_cuts_follow_the_weights():
     c3 = parallel.orb_cuts(pts, 3, w)
     work3 = np.bincount(parallel.orb_assign(c3, pts), weights=w, minlength=3)
     assert work3.max() < 1.02 * work3.mean()
+
+
+def test_cuts_snap_to_coarse_cell_boundaries():
+    """A bisection of a centred sphere puts its median a hair beside x = domain/2, the boundary
+    of the coarsest Morton cells; with `grid` the cut moves onto it, so that no domain holds
+    a thin slab of particles on the far side."""
+    S = (1 << 21) - 1
+    assert parallel.snap_to_cells(2.4999, 2.5002, (5.0, 21)) == (1 << 20) * 5.0 / S
+    assert parallel.snap_to_cells(1.0, 1.0000001, (5.0, 21)) is None          # no boundary inside
+    got = parallel.snap_to_cells(2.51, 2.52, (5.0, 21)) * S / 5.0
+    assert got == round(got) and int(round(got)) % (1 << 12) == 0            # the roundest in range
+    rng = np.random.default_rng(5)
+    n = 200000
+    r = 0.5 * rng.uniform(0, 1, n) ** (1 / 3)
+    ct, ph = rng.uniform(-1, 1, n), rng.uniform(0, 2 * np.pi, n)
+    st = np.sqrt(1 - ct * ct)
+    x, y, z = 2.5 + r * st * np.cos(ph), 2.5 + r * st * np.sin(ph), 2.5 + r * ct
+    half = (1 << 20) * 5.0 / S
+    plain = parallel.domain_slices(x, y, z, 8)
+    snapped = parallel.domain_slices(x, y, z, 8, grid=(5.0, 21))
+    assert sorted(np.concatenate(snapped).tolist()) == list(range(n))       # still a partition
+    assert max(len(p) for p in snapped) < 1.02 * n / 8                      # within the slack
+    def straddlers(parts):
+        k = 0
+        for p in parts:
+            for a in (x, y, z):
+                lo, hi = (a[p] < half).sum(), (a[p] >= half).sum()
+                k += min(lo, hi)                                            # the minority side
+        return k
+    assert straddlers(plain) > 0 and straddlers(snapped) == 0
+    # the same rule in the re-balancing cuts
+    pts = np.stack([x, y, z], 1)
+    dom = parallel.orb_assign(parallel.orb_cuts(pts, 8, grid=(5.0, 21)), pts)
+    assert straddlers([np.nonzero(dom == d)[0] for d in range(8)]) == 0
