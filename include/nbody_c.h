@@ -50,9 +50,10 @@ enum {
                                           and centres of mass in double and runs every
                                           floating-point stage in double.  The parameters stay
                                           float, as in the reference (include/simulation.hpp:21-26).
-                                          Every entry point works on such a handle except the
-                                          multi-GPU ones (traversal range, finish_step, bbox,
-                                          let_export, set_sources_dev, traverse_from);
+                                          Every entry point works on such a handle except those of
+                                          the domain decomposition (bbox, let_export,
+                                          set_sources_dev, traverse_from); the sharded traversal
+                                          (traversal range, finish_step) does;
                                           float arguments are widened and
                                           float results narrowed, the *_f64 entry points move
                                           doubles unchanged.                                     */

@@ -820,10 +820,10 @@ int nbody_update(nbody_t *h)
     NB_HIP(s, mark(EV_BUILD));
     NB_HIP(s, s->fp64 ? launch64_com(s) : launch_com(s));
     NB_HIP(s, mark(EV_COM));
-    if (s->fp64) {   // a double handle is never sharded (nbody_set_traversal_range refuses it)
+    if (s->fp64) {
         NB_HIP(s, launch64_export_view(s));
         NB_HIP(s, launch64_traverse(s, false));
-        NB_HIP(s, launch64_vel_kick(s));
+        if (!sharded) NB_HIP(s, launch64_vel_kick(s));
     } else {
         NB_HIP(s, launch_export_view(s));
         NB_HIP(s, launch_traverse(s, fuse));
@@ -844,9 +844,8 @@ int nbody_update(nbody_t *h)
 int nbody_finish_step(nbody_t *h)
 {
     NB_ENTER(h);
-    NB_FLOAT_ONLY(s, "finish_step");
     if (!s->pending_vel) return fail(s, NBODY_ERR_STATE, "no sharded step pending");
-    NB_HIP(s, launch_vel_kick(s));
+    NB_HIP(s, s->fp64 ? launch64_vel_kick(s) : launch_vel_kick(s));
     s->pending_vel = false;
     return NBODY_OK;
 }
@@ -854,7 +853,6 @@ int nbody_finish_step(nbody_t *h)
 int nbody_set_traversal_range(nbody_t *h, int32_t g0, int32_t g1)
 {
     NB_ENTER(h);
-    NB_FLOAT_ONLY(s, "set_traversal_range");
     const int ngroups = (s->n + s->group - 1) / s->group;
     if (g1 >= 0 && (g0 < 0 || g0 > g1 || g1 > ngroups))
         return fail(s, NBODY_ERR_INVALID, "traversal range outside [0, ngroups]");

@@ -258,15 +258,15 @@ struct alignas(16) T64Lds {
 
 template <int G, bool POT>
 __global__ __launch_bounds__(64 * T64_WAVES) void k64_traverse(
-    int n, int ngroups, const Double4 *__restrict__ posm, const Double4 *__restrict__ nodeA,
+    int n, int g0, int ngroups, const Double4 *__restrict__ posm, const Double4 *__restrict__ nodeA,
     const NodeB *__restrict__ nodeB, double theta2, double eps2, double gravity, double dinit,
     double *__restrict__ ax, double *__restrict__ ay, double *__restrict__ az,
     double *__restrict__ pot, uint32_t *__restrict__ list_len, uint32_t *err, int stack_cap)
 {
     __shared__ T64Lds lds[T64_WAVES];
     const int lane = (int) threadIdx.x & 63, w = (int) threadIdx.x >> 6;
-    const int g = (int) blockIdx.x * T64_WAVES + w;
-    if (g >= ngroups) return;   // whole wave; the kernel has no workgroup barrier
+    if ((int) blockIdx.x * T64_WAVES + w >= ngroups) return;   // whole wave; no workgroup barrier here
+    const int g = g0 + (int) blockIdx.x * T64_WAVES + w;
     T64Lds &L = lds[w];
     const int b0 = g * G;
     const int nb = min(G, n - b0);
@@ -555,7 +555,12 @@ hipError_t launch64_com(Sim *s)
 hipError_t launch64_traverse(Sim *s, bool potential)
 {
     State64 &d = s->d;
-    const int ngroups = (s->n + s->group - 1) / s->group;
+    const int all = (s->n + s->group - 1) / s->group;
+    // the step's traversal covers the range set by nbody_set_traversal_range; the potential
+    // always covers every group
+    const int g0 = (potential || s->trav_g1 < 0) ? 0 : s->trav_g0;
+    const int g1 = (potential || s->trav_g1 < 0) ? all : std::min(s->trav_g1, all);
+    const int ngroups = g1 - g0;
     if (ngroups < 1) return hipSuccess;
     const int grid = (ngroups + T64_WAVES - 1) / T64_WAVES;
     const double theta = (double) s->p.theta, eps = (double) s->p.softening_factor;
@@ -564,7 +569,7 @@ hipError_t launch64_traverse(Sim *s, bool potential)
     const int stack_cap = (s->p.flags & NBODY_FLAG_DEBUG_SMALL_STACK) ? T64_RESERVE + 32 : T64_STACK;
 #define NB_T64(GG, PP)                                                                           \
     hipLaunchKernelGGL((k64_traverse<GG, PP>), dim3(grid), dim3(64 * T64_WAVES), 0, s->stream,    \
-                       s->n, ngroups, d.posm, d.nodeA, s->nodeB, theta * theta, eps * eps,        \
+                       s->n, g0, ngroups, d.posm, d.nodeA, s->nodeB, theta * theta, eps * eps,    \
                        (double) s->p.gravity, dom * dom * 3.0, d.ax, d.ay, d.az, d.pot,           \
                        s->list_len, &s->counts->err, stack_cap)
     if (s->group == 64) { if (potential) NB_T64(64, true); else NB_T64(64, false); }

@@ -339,16 +339,18 @@ class GpuBackend:
     """ShardedTraversal backend over a nbody_amd.Simulation (all particles on every rank)."""
 
     class _Dev:
-        def __init__(self, ptr, n):
-            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False),
+        def __init__(self, ptr, n, typestr):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False),
                                              "version": 2}
 
     def __init__(self, sim, device):
         self.sim = sim
         self.n = sim.params.num_points
         self.group = sim.params.traversal_group_size
-        v = sim.device_view()
-        self._acc = [torch.as_tensor(self._Dev(p, self.n), device=device) for p in (v.ax, v.ay, v.az)]
+        # the library's acceleration arrays, zero-copy: float32, or float64 for a handle
+        # created with FLAG_FP64
+        v, ts = (sim.device_view_f64(), "<f8") if sim.fp64 else (sim.device_view(), "<f4")
+        self._acc = [torch.as_tensor(self._Dev(p, self.n, ts), device=device) for p in (v.ax, v.ay, v.az)]
 
     def set_traversal_range(self, g0, g1):
         self.sim.set_traversal_range(g0, g1)
@@ -364,19 +366,6 @@ class GpuBackend:
 
     def finish_step(self):
         self.sim.finish_step()
-
-    def work_weights(self):
-        """Per particle (current order): sources its group met in the own tree plus in the
-        imported tree.  Runs both traversals again to read their list lengths one after the
-        other; the accelerations come out as they were (same inputs, same sums)."""
-        import numpy as np
-        self.sim.traverse_from(self.sim, accumulate=False)
-        per_group = self.sim.get_list_len().astype(np.float64)
-        if self.remote is not None and self.remote.count() > 0:
-            self.sim.traverse_from(self.remote, accumulate=True)
-            per_group += self.sim.get_list_len()
-        n = self.sim.count()
-        return np.repeat(per_group, self.sim.params.traversal_group_size)[:n]
 
     def get_particles(self):
         return self.sim.get_state()

@@ -213,14 +213,38 @@ def test_fp64_float_arguments_are_converted_and_snapshot_restarts(tmp_path):
         assert sim.get_state()["x"].dtype == np.float32
 
 
-def test_fp64_multi_gpu_calls_are_refused_and_views():
+def test_fp64_sharded_traversal_equals_whole():
+    """nbody_set_traversal_range / nbody_finish_step on a double handle: two group ranges computed
+    one after the other give the accelerations and velocities of the single-GPU step, bit for bit."""
+    n = 10000
+    ic = make_ic64("clusters", n, seed=5)
+    args = (ic["x"], ic["y"], ic["z"], ic["m"], ic["vx"], ic["vy"], ic["vz"])
+    with new_sim64(n, morton_bits=21, theta=0.5, dt=1e-3) as sim:
+        sim.set_state(*args)
+        sim.update()
+        whole = sim.get_state()
+    ngroups = (n + 63) // 64
+    for g0, g1 in ((0, ngroups // 2), (ngroups // 2, ngroups)):
+        with new_sim64(n, morton_bits=21, theta=0.5, dt=1e-3) as sim:
+            sim.set_state(*args)
+            sim.set_traversal_range(g0, g1)
+            sim.update()
+            sim.finish_step()
+            st = sim.get_state()
+        b0, b1 = g0 * 64, min(g1 * 64, n)
+        for k in ("ax", "ay", "az", "vx"):
+            assert np.array_equal(st[k][b0:b1], whole[k][b0:b1]), k
+
+
+def test_fp64_domain_decomposition_calls_are_refused_and_views():
     n = 1000
     ic = make_ic64("uniform", n)
     with new_sim64(n) as sim:
         sim.set_state(ic["x"], ic["y"], ic["z"], ic["m"])
-        for call in (lambda: sim.set_traversal_range(0, 1), sim.finish_step, sim.get_bbox):
-            with pytest.raises(RuntimeError, match="double-precision"):
-                call()
+        with pytest.raises(RuntimeError, match="double-precision"):
+            sim.get_bbox()
+        with pytest.raises(RuntimeError, match="double-precision"):
+            sim.traverse_from(sim, accumulate=False)
         v32, v64 = sim.device_view(), sim.device_view_f64()
         assert v32.n == n and not v32.x and not v32.posm
         assert v64.n == n and v64.x and v64.posm and v64.stream

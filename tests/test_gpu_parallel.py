@@ -57,10 +57,12 @@ def single_rank_group():
     dist.destroy_process_group()
 
 
-def test_sharded_stepper_single_rank_matches_plain_update(single_rank_group):
+@pytest.mark.parametrize("flags", [0, nb.FLAG_FP64])
+def test_sharded_stepper_single_rank_matches_plain_update(single_rank_group, flags):
     n = 8192
     ic = nb.sample_ic(nb.IC_DISK, n, 3)
-    kw = dict(num_points=n, morton_bits=21, theta=0.5, dt=1e-3, softening_factor=0.01, device_id=0)
+    kw = dict(num_points=n, morton_bits=21, theta=0.5, dt=1e-3, softening_factor=0.01, device_id=0,
+              flags=flags)
     with nb.Simulation(nb.Params(**kw)) as a, nb.Simulation(nb.Params(**kw)) as b:
         for s in (a, b):
             s.set_state(ic["x"], ic["y"], ic["z"], ic["m"], ic["vx"], ic["vy"], ic["vz"])
