@@ -512,3 +512,48 @@ def test_largest_configuration_properties_and_sampled_accuracy():
         err.append(np.linalg.norm(got - ref) / np.linalg.norm(ref))
     err = np.array(err)
     assert err.mean() < 2e-3 and err.max() < 3e-2, (err.mean(), err.max())
+
+
+import glob
+import os
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_library_against_committed_fixtures(path):
+    """The committed oracle outputs (tests/golden, written by make_golden.py) as the target:
+    build products and list lengths bit for bit, accelerations to 1e-4, the state after three
+    steps to 1e-4 in position (forces differ in their last bits and close pairs at eps = 0.01
+    amplify that over the steps)."""
+    g = np.load(path)
+    bits, max_codes, group = (int(v) for v in g["params"])
+    theta, eps, dt, domain, grav = (float(v) for v in g["fparams"])
+    p, v, m = g["pos"], g["vel"], g["mass"]
+    n = len(m)
+    kw = dict(morton_bits=bits, max_num_codes_per_leaf=max_codes, traversal_group_size=group, theta=theta,
+              softening_factor=eps, domain_size=domain, gravity=grav)
+    with new_sim(n, dt=0.0, **kw) as sim:
+        sim.set_state(p[:, 0], p[:, 1], p[:, 2], m)
+        t = sim.get_octree()
+        sim.update()
+        ll = sim.get_list_len()
+        st = sim.get_state()
+    for k in ("codes_sorted", "perm", "unique", "first_pt", "leaf_first_code_idx"):
+        assert np.array_equal(t[k], g[k]), k
+    for k in TOPO + ("size",):
+        assert np.array_equal(t[k], g["tree_" + k]), k
+    for k in ("comx", "comy", "comz", "mass"):
+        assert np.array_equal(t[k], g["com_" + k]), k
+    assert np.array_equal(ll, g["list_len"])
+    ref = np.stack([g["ax"], g["ay"], g["az"]]).astype(np.float64)
+    err = np.sqrt(((np.stack([st["ax"], st["ay"], st["az"]]) - ref) ** 2).sum(0)) / np.sqrt((ref ** 2).sum(0))
+    assert err.max() < 1e-4
+    with new_sim(n, dt=dt, **kw) as sim:
+        sim.set_state(p[:, 0], p[:, 1], p[:, 2], m, v[:, 0], v[:, 1], v[:, 2])
+        sim.step(3)
+        s3 = sim.get_state()
+        assert sim.tree_counts() == tuple(int(c) for c in g["counts_after_3"])
+    assert np.array_equal(s3["id"], g["after3_id"])
+    for k in ("x", "y", "z"):
+        assert np.max(np.abs(s3[k] - g["after3_" + k])) < 1e-4, k

@@ -407,3 +407,41 @@ def test_dp_sim_two_body_orbit_and_float_sim_closeness():
     assert a.counts()[:3] == b.counts()[:3]
     assert np.array_equal(sa["id"], sb["id"])
     assert np.max(np.abs(sa["x"] - sb["x"])) < 1e-5
+
+
+# ------------------------------------------------------------------ committed fixtures
+import glob
+import os
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_oracle_reproduces_committed_fixtures(path):
+    """tests/golden/*.npz were written by tests/golden/make_golden.py from this oracle: every
+    integer array bit for bit, every float bit for bit too (the oracle's float path is plain
+    IEEE arithmetic with written-out fma, deterministic across machines and thread counts)."""
+    g = np.load(path)
+    bits, max_codes, group = (int(v) for v in g["params"])
+    theta, eps, dt, domain, grav = (float(v) for v in g["fparams"])
+    p, v, m = g["pos"], g["vel"], g["mass"]
+    b = O.full_build(p[:, 0], p[:, 1], p[:, 2], m, domain, bits, max_codes)
+    for k in ("codes_sorted", "perm", "unique", "first_pt", "leaf_first_code_idx"):
+        assert np.array_equal(b[k], g[k]), k
+    for k, a in b["tree"].items():
+        if k != "n_oct":
+            assert np.array_equal(a, g["tree_" + k]), k
+    for k, a in b["com"].items():
+        assert np.array_equal(a, g["com_" + k]), k
+    ax, ay, az, ll = O.traverse(b["tree"], b["com"], b["xs"], b["ys"], b["zs"], b["ms"], group, theta,
+                                eps, grav, domain)
+    assert np.array_equal(ll, g["list_len"])
+    assert np.array_equal(ax, g["ax"]) and np.array_equal(ay, g["ay"]) and np.array_equal(az, g["az"])
+    sim = O.OracleSim(p[:, 0], p[:, 1], p[:, 2], m, v[:, 0], v[:, 1], v[:, 2], bits=bits,
+                      max_codes=max_codes, group=group, theta=theta, dt=dt, eps=eps)
+    for _ in range(3):
+        sim.step()
+    s3 = sim.state()
+    assert tuple(sim.counts()[:3]) == tuple(int(c) for c in g["counts_after_3"])
+    for k in ("x", "y", "z", "vx", "vy", "vz", "id"):
+        assert np.array_equal(s3[k], g["after3_" + k]), k
