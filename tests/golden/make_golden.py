@@ -64,6 +64,30 @@ def make(case):
     print(name, "n_oct", b["tree"]["n_oct"], "interactions", int(ll.sum()))
 
 
+def make_dp():
+    """The oracle's double instantiation on double-precision inputs (not float-representable)."""
+    rng = np.random.default_rng(3)
+    n, bits, max_codes, group, theta, eps = 2000, 21, 16, 64, 0.6, 0.01
+    c = rng.uniform(1, 4, (4, 3))
+    p = (c[rng.integers(0, 4, n)] + rng.normal(0, 0.05, (n, 3))).clip(0, 5)
+    m = rng.uniform(0.5, 1.5, n)
+    b = O.full_build_dp(p[:, 0], p[:, 1], p[:, 2], m, 5.0, bits, max_codes)
+    ax, ay, az, ll = O.traverse_dp(b["tree"], b["com"], b["xs"], b["ys"], b["zs"], b["ms"], group,
+                                   theta, eps, 1.0, 5.0)
+    out = dict(pos=p, mass=m, params=np.array([bits, max_codes, group], np.int32),
+               fparams=np.array([theta, eps, 0.0, 5.0, 1.0], np.float32),
+               codes_sorted=b["codes_sorted"], perm=b["perm"], leaf_first_code_idx=b["leaf_first_code_idx"],
+               list_len=ll, ax=ax, ay=ay, az=az)
+    for k, a in b["com"].items():
+        out["com_" + k] = a
+    for k in ("num_children", "points_begin", "points_end", "level"):
+        out["tree_" + k] = b["tree"][k]
+    np.savez_compressed(os.path.join(HERE, "double", "clusters_dp_b21_g64.npz"), **out)
+    print("clusters_dp_b21_g64 n_oct", b["tree"]["n_oct"], "interactions", int(ll.sum()))
+
+
 if __name__ == "__main__":
     for c in CASES:
         make(c)
+    os.makedirs(os.path.join(HERE, "double"), exist_ok=True)
+    make_dp()

@@ -329,3 +329,27 @@ def test_fp64_headline_workload_lists_match_oracle():
                                    64, theta, eps, 1.0, 5.0)
     assert np.array_equal(gpu["list_len"], ll)
     assert rel_err((st["ax"], st["ay"], st["az"]), (ax, ay, az)) < 1e-12
+
+
+def test_fp64_library_against_committed_fixture():
+    """tests/golden/double (written by make_golden.py from the oracle's double instantiation)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "double", "clusters_dp_b21_g64.npz"))
+    bits, max_codes, group = (int(v) for v in g["params"])
+    theta, eps = float(g["fparams"][0]), float(g["fparams"][1])
+    p, m = g["pos"], g["mass"]
+    with new_sim64(len(m), morton_bits=bits, max_num_codes_per_leaf=max_codes, traversal_group_size=group,
+                   theta=theta, softening_factor=eps, dt=0.0) as sim:
+        sim.set_state(p[:, 0], p[:, 1], p[:, 2], m)
+        t = sim.get_octree()
+        sim.update()
+        ll = sim.get_list_len()
+        st = sim.get_state()
+    for k in ("codes_sorted", "perm", "leaf_first_code_idx"):
+        assert np.array_equal(t[k], g[k]), k
+    for k in ("num_children", "points_begin", "points_end", "level"):
+        assert np.array_equal(t[k], g["tree_" + k]), k
+    for k in ("comx", "comy", "comz", "mass"):
+        assert np.array_equal(t[k], g["com_" + k]), k
+    assert np.array_equal(ll, g["list_len"])
+    assert rel_err((st["ax"], st["ay"], st["az"]), (g["ax"], g["ay"], g["az"])) < 1e-12

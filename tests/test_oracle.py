@@ -445,3 +445,23 @@ def test_oracle_reproduces_committed_fixtures(path):
     assert tuple(sim.counts()[:3]) == tuple(int(c) for c in g["counts_after_3"])
     for k in ("x", "y", "z", "vx", "vy", "vz", "id"):
         assert np.array_equal(s3[k], g["after3_" + k]), k
+
+
+def test_double_oracle_reproduces_committed_fixture():
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "double", "clusters_dp_b21_g64.npz"))
+    bits, max_codes, group = (int(v) for v in g["params"])
+    theta, eps = float(g["fparams"][0]), float(g["fparams"][1])
+    p, m = g["pos"], g["mass"]
+    assert p.dtype == np.float64
+    b = O.full_build_dp(p[:, 0], p[:, 1], p[:, 2], m, 5.0, bits, max_codes)
+    for k in ("codes_sorted", "perm", "leaf_first_code_idx"):
+        assert np.array_equal(b[k], g[k]), k
+    for k in ("num_children", "points_begin", "points_end", "level"):
+        assert np.array_equal(b["tree"][k], g["tree_" + k]), k
+    for k, a in b["com"].items():
+        assert np.array_equal(a, g["com_" + k]), k
+    ax, ay, az, ll = O.traverse_dp(b["tree"], b["com"], b["xs"], b["ys"], b["zs"], b["ms"], group, theta,
+                                   eps, 1.0, 5.0)
+    assert np.array_equal(ll, g["list_len"])
+    # libm's sqrt and the divide are correctly rounded, fma is written out: same bits anywhere
+    assert np.array_equal(ax, g["ax"]) and np.array_equal(ay, g["ay"]) and np.array_equal(az, g["az"])
