@@ -28,3 +28,4 @@ oc = s.get_octree()
 print("codes", [hex(int(c)) for c in oc["codes_sorted"][sl][[0, 1, 32, 63]]])
 zc = st["z"]
 print("particles with z >= 2.4999:", int((zc >= 2.4999).sum()), "max z", zc.max(), "count z==max", int((zc == zc.max()).sum()))
+print("low quantiles / mean:", [round(float(np.quantile(ll, q) / ll.mean()), 3) for q in (0.01, 0.05, 0.1, 0.15, 0.2, 0.3)])
