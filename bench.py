@@ -472,7 +472,7 @@ def main():
         if f64 is not None:
             out["other_precision"] = f64
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ic, args.morton_bits, eps=eps)
+            out["cpu_baseline"] = cpu_baseline(ic, args.morton_bits, steps=5, eps=eps)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
