@@ -100,11 +100,14 @@ int nbody_create(const nbody_params *params, nbody_t **out);
 /* Simulation(Params&, GLuint buffers[7])  (reference: include/simulation.hpp:31,
  * src/cuda/simulation.cu:39-51,138-158): the viewer-owned buffers
  * [pos.x, pos.y, pos.z, com.x, com.y, com.z, node_size].  The reference maps seven GL buffers
- * and uses them as storage; here dev_ptrs are seven caller-owned DEVICE pointers to float --
- * the first three with room for num_points values, the last four for 2*num_points (one per
+ * and uses them as storage; here dev_ptrs are seven caller-owned DEVICE pointers -- the first
+ * three with room for num_points ELEMENTS, the last four for 2*num_points elements (one per
  * octree node) -- into which the library copies the current positions (sorted order) and
  * the octree nodes' centres of mass and sizes after every spawn/set_state/update, on the
- * handle's stream.  NULL entries are skipped; dev_ptrs == NULL equals nbody_create. */
+ * handle's stream.  An element has the handle's precision: float (4 bytes), or double
+ * (8 bytes) on a handle created with NBODY_FLAG_FP64 -- size the buffers accordingly (the
+ * reference sizes its buffers for double in either case, src/renderer.cpp:255-267).
+ * NULL entries are skipped; dev_ptrs == NULL equals nbody_create. */
 int nbody_create_external(const nbody_params *params, void *dev_ptrs[7], nbody_t **out);
 /* ~Simulation() (include/simulation.hpp:38). */
 void nbody_destroy(nbody_t *sim);
@@ -228,7 +231,10 @@ int nbody_get_octree_com_f64(nbody_t *sim, double *comx, double *comy, double *c
 /* Per-stage device times (ms, HIP events on the handle's stream) summed over the steps
  * run since the last call, and the number of steps summed; needs NBODY_FLAG_TIMING.
  * Without NBODY_FLAG_TIMING_STAGES only ms_traverse and ms_total are split out and
- * ms_build holds everything before the traversal.  Traversals driven through
+ * ms_build holds everything before the traversal.  The library keeps the events of the last
+ * 64 steps; records older than that are folded into host-side sums as steps go on (the
+ * 65th nbody_update() since the last call may therefore wait for the oldest of those steps
+ * to finish), so any number of steps may pass between two calls.  Traversals driven through
  * nbody_traverse_from (at most two per step) count into ms_traverse, ms_total and
  * interactions of the step that precedes them.
  * interactions = sum over those steps of sum_g list_len[g] * bodies_in_group(g). */
@@ -255,7 +261,10 @@ int nbody_tree_energy(nbody_t *sim, double *kinetic, double *potential);
 /* Checkpoint / restart.  The reference has no state I/O (its particles only ever come from
  * include/cuda/initial_conditions.cuh).  The file holds x,y,z,vx,vy,vz,m,ax,ay,az and the ids
  * of all particles in the handle's current (sorted) order; a handle with the same parameters
- * that loads it continues bit-identically to the run that saved it.  The validator's all-pairs
+ * that loads it continues bit-identically to the run that saved it.  The file may hold fewer
+ * particles than the loading handle's num_points (a handle created with head-room); its
+ * domain_size must equal the handle's.  Not available between nbody_update() and
+ * nbody_finish_step() of a sharded step.  The validator's all-pairs
  * twin is not part of the file.  A handle with NBODY_FLAG_FP64 writes doubles; a file of the
  * other precision loads with conversion. */
 int nbody_save_snapshot(nbody_t *sim, const char *path);
@@ -275,6 +284,20 @@ int nbody_direct_sum(nbody_t *sim, float *ax, float *ay, float *az);
  * masses widened, which is the accuracy reference for the float tree forces at sizes a host
  * loop cannot reach. */
 int nbody_direct_sum_f64(nbody_t *sim, double *ax, double *ay, double *az);
+
+/* Total energy of n bodies by direct summation, reduced on the device (reference:
+ * compute_conserved_quantities and the cub::DeviceReduce::Sum calls behind it,
+ * src/cuda/validator.cu:19-36,65-132,278-287).  posm = n float4 (x,y,z,m) and vx,vy,vz = n
+ * floats each, all device arrays; out_dev = two device doubles:
+ *   out_dev[0] = sum_i m_i |v_i|^2 / 2
+ *   out_dev[1] = -gravity/2 sum_i m_i sum_{j != i} m_j / sqrt(d_ij^2 + softening_factor^2).
+ * Per-body potential sums are float like the force kernels, the sums over bodies double and
+ * independent of scheduling.  The call allocates and frees a scratch buffer of 16 bytes per
+ * 256 bodies and therefore returns only when the result is in out_dev.  stream = hipStream_t
+ * or NULL; the stream's device must be current. */
+int nbody_direct_energy_dev(const float *posm, const float *vx, const float *vy, const float *vz,
+                            int32_t n, float softening_factor, float gravity, double *out_dev,
+                            void *stream);
 
 /* Multi-GPU sharded traversal: restrict nbody_update()'s traversal to groups
  * [group_begin, group_end) of the sorted order; the caller (one process per GPU) then

@@ -56,6 +56,8 @@ void free_all(Sim *s)
     F(s->o_le); F(s->o_level); F(s->o_pb); F(s->o_pe); F(s->o_parent); F(s->o_size); F(s->o_wsum);
     F(s->nodeA); F(s->nodeB); F(s->list_len); F(s->inter_dev); F(s->trav_tail); F(s->trav_heavy_ctrl); F(s->pot);
     F(s->tw_posm); F(s->tw_pot); F(s->ds_pot); F(s->let_boxes); F(s->let_counts);
+    F(s->red_scratch); F(s->red_out);
+    if (s->red_host) (void) hipHostFree(s->red_host);
     for (int k = 0; k < 3; ++k) { F(s->tw_v[k]); F(s->tw_vh[k]); F(s->tw_a[k]); F(s->ds_a[k]); }
     State64 &d = s->d;
     for (int i = 0; i < 2; ++i) {
@@ -182,6 +184,11 @@ int alloc_all(Sim *s)
     }
     NB_HIP(s, dalloc(&s->let_boxes, (size_t) 6 * LET_MAX_BOXES));
     NB_HIP(s, dalloc(&s->let_counts, (size_t) LET_MAX_BOXES + 8));
+    const size_t red_bytes = reduce_scratch_bytes(REDUCE_MAX_BLOCKS, 3);
+    NB_HIP(s, hipMalloc((void **) &s->red_scratch, red_bytes));
+    NB_HIP(s, hipMemsetAsync(s->red_scratch, 0, red_bytes, s->stream));
+    NB_HIP(s, dalloc(&s->red_out, 8));
+    NB_HIP(s, hipHostMalloc((void **) &s->red_host, 8 * sizeof(double)));
     NB_HIP(s, dalloc(&s->inter_dev, (size_t) TIMING_RING));
     NB_HIP(s, hipMemsetAsync(s->inter_dev, 0, TIMING_RING * 8, s->stream));
     if (s->p.num_steps_validator > 0 && s->fp64) {
@@ -332,6 +339,8 @@ int build_after_encode(Sim *s, bool permute_all)
 int post_spawn(Sim *s)
 {
     const size_t n = (size_t) s->n;
+    // a fresh particle set starts with a clean device error word (the build rewrites the counts)
+    NB_HIP(s, hipMemsetAsync(s->counts, 0, sizeof(Counts), s->stream));
     if (s->fp64) {
         NB_HIP(s, hipMemsetAsync(s->d.ax, 0, n * 8, s->stream));
         NB_HIP(s, hipMemsetAsync(s->d.ay, 0, n * 8, s->stream));
@@ -351,6 +360,7 @@ int post_spawn(Sim *s)
     s->spawned = true;
     s->pending_vel = false;
     s->ev_pending = 0;
+    s->t_acc = nbody_timings{};
     s->hist_e.clear(); s->hist_e_ap.clear(); s->hist_err.clear();
     s->val_count = 0;
     return fetch_counts(s);
@@ -466,33 +476,17 @@ int validator_step(Sim *s)
     NB_HIP(s, launch_vel_kick_raw(n, s->p.dt, 1.0f - s->p.velocity_dampening, s->tw_vh[0],
                                   s->tw_vh[1], s->tw_vh[2], s->tw_a[0], s->tw_a[1], s->tw_a[2],
                                   s->tw_v[0], s->tw_v[1], s->tw_v[2], s->stream));
-    std::vector<float> a[3], d[3], v[3], tv[3], pot(n), tpot(n), m(n);
-    std::vector<Float4> tp(n);
+    // the three sums are reduced on the device (reference: cub::DeviceReduce::Sum,
+    // src/cuda/validator.cu:261-287); six doubles cross PCIe per record
     const float *acc[3] = {s->ax, s->ay, s->az};
-    const float *vel[3] = {s->vx[c], s->vy[c], s->vz[c]};
-    for (int k = 0; k < 3; ++k) {
-        a[k].resize(n); d[k].resize(n); v[k].resize(n); tv[k].resize(n);
-        NB_HIP(s, hipMemcpyAsync(a[k].data(), acc[k], b, hipMemcpyDeviceToHost, s->stream));
-        NB_HIP(s, hipMemcpyAsync(d[k].data(), s->ds_a[k], b, hipMemcpyDeviceToHost, s->stream));
-        NB_HIP(s, hipMemcpyAsync(v[k].data(), vel[k], b, hipMemcpyDeviceToHost, s->stream));
-        NB_HIP(s, hipMemcpyAsync(tv[k].data(), s->tw_v[k], b, hipMemcpyDeviceToHost, s->stream));
-    }
-    NB_HIP(s, hipMemcpyAsync(pot.data(), s->ds_pot, b, hipMemcpyDeviceToHost, s->stream));
-    NB_HIP(s, hipMemcpyAsync(tpot.data(), s->tw_pot, b, hipMemcpyDeviceToHost, s->stream));
-    NB_HIP(s, hipMemcpyAsync(m.data(), s->m[c], b, hipMemcpyDeviceToHost, s->stream));
-    NB_HIP(s, hipMemcpyAsync(tp.data(), s->tw_posm, (size_t) n * sizeof(Float4), hipMemcpyDeviceToHost,
-                             s->stream));
+    NB_HIP(s, launch_energy_reduce(n, s->m[c], 1, s->vx[c], s->vy[c], s->vz[c], s->ds_pot, (double) G,
+                                   acc, s->ds_a, s->red_scratch, s->red_out, s->stream));
+    NB_HIP(s, launch_energy_reduce(n, &s->tw_posm[0].w, 4, s->tw_v[0], s->tw_v[1], s->tw_v[2], s->tw_pot,
+                                   (double) G, nullptr, nullptr, s->red_scratch, s->red_out + 3, s->stream));
+    NB_HIP(s, hipMemcpyAsync(s->red_host, s->red_out, 6 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     NB_HIP(s, hipStreamSynchronize(s->stream));
-    double e = 0, e_ap = 0, err = 0;
-    for (int i = 0; i < n; ++i) {
-        const double v2 = (double) v[0][i] * v[0][i] + (double) v[1][i] * v[1][i] + (double) v[2][i] * v[2][i];
-        e += m[i] * (0.5 * v2 - 0.5 * G * pot[i]);
-        const double w2 = (double) tv[0][i] * tv[0][i] + (double) tv[1][i] * tv[1][i] + (double) tv[2][i] * tv[2][i];
-        e_ap += tp[i].w * (0.5 * w2 - 0.5 * G * tpot[i]);
-        const double dx = a[0][i] - d[0][i], dy = a[1][i] - d[1][i], dz = a[2][i] - d[2][i];
-        const double dn = std::sqrt((double) d[0][i] * d[0][i] + (double) d[1][i] * d[1][i] + (double) d[2][i] * d[2][i]);
-        if (dn > 0) err += std::sqrt(dx * dx + dy * dy + dz * dz) / dn;
-    }
+    const double e = s->red_host[0] + s->red_host[1], e_ap = s->red_host[3] + s->red_host[4];
+    const double err = s->red_host[2];
     const size_t cap = (size_t) s->p.num_steps_validator;
     if (s->hist_e.size() < cap) { s->hist_e.resize(cap); s->hist_e_ap.resize(cap); s->hist_err.resize(cap); }
     s->hist_e[s->val_step] = e;
@@ -517,30 +511,15 @@ int validator_step64(Sim *s)
     NB_HIP(s, launch64_twin_kick_drift(n, dt, (double) s->p.domain_size, d.tw_posm, d.tw_v, d.tw_a, d.tw_vh, s->stream));
     NB_HIP(s, launch64_direct(d.tw_posm, n, d.tw_posm, n, eps2, G, d.tw_a[0], d.tw_a[1], d.tw_a[2], d.tw_pot, 1, s->stream));
     NB_HIP(s, launch64_vel_kick_raw(n, dt, 1.0 - (double) s->p.velocity_dampening, d.tw_vh, d.tw_a, d.tw_v, s->stream));
-    std::vector<double> a[3], ds[3], v[3], tv[3], pot(n), tpot(n), m(n);
-    std::vector<Double4> tp(n);
     const double *acc[3] = {d.ax, d.ay, d.az};
-    const double *vel[3] = {d.vx[c], d.vy[c], d.vz[c]};
-    for (int k = 0; k < 3; ++k) {
-        a[k].resize(n); ds[k].resize(n); v[k].resize(n); tv[k].resize(n);
-        NB_HIP(s, hipMemcpyAsync(a[k].data(), acc[k], b, hipMemcpyDeviceToHost, s->stream));
-        NB_HIP(s, hipMemcpyAsync(ds[k].data(), d.ds_a[k], b, hipMemcpyDeviceToHost, s->stream));
-        NB_HIP(s, hipMemcpyAsync(v[k].data(), vel[k], b, hipMemcpyDeviceToHost, s->stream));
-        NB_HIP(s, hipMemcpyAsync(tv[k].data(), d.tw_v[k], b, hipMemcpyDeviceToHost, s->stream));
-    }
-    NB_HIP(s, hipMemcpyAsync(pot.data(), d.ds_pot, b, hipMemcpyDeviceToHost, s->stream));
-    NB_HIP(s, hipMemcpyAsync(tpot.data(), d.tw_pot, b, hipMemcpyDeviceToHost, s->stream));
-    NB_HIP(s, hipMemcpyAsync(m.data(), d.m[c], b, hipMemcpyDeviceToHost, s->stream));
-    NB_HIP(s, hipMemcpyAsync(tp.data(), d.tw_posm, (size_t) n * sizeof(Double4), hipMemcpyDeviceToHost, s->stream));
+    NB_HIP(s, launch_energy_reduce64(n, d.m[c], 1, d.vx[c], d.vy[c], d.vz[c], d.ds_pot, G, acc, d.ds_a,
+                                     s->red_scratch, s->red_out, s->stream));
+    NB_HIP(s, launch_energy_reduce64(n, &d.tw_posm[0].w, 4, d.tw_v[0], d.tw_v[1], d.tw_v[2], d.tw_pot, G,
+                                     nullptr, nullptr, s->red_scratch, s->red_out + 3, s->stream));
+    NB_HIP(s, hipMemcpyAsync(s->red_host, s->red_out, 6 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     NB_HIP(s, hipStreamSynchronize(s->stream));
-    double e = 0, e_ap = 0, err = 0;
-    for (int i = 0; i < n; ++i) {
-        e += m[i] * (0.5 * (v[0][i] * v[0][i] + v[1][i] * v[1][i] + v[2][i] * v[2][i]) - 0.5 * G * pot[i]);
-        e_ap += tp[i].w * (0.5 * (tv[0][i] * tv[0][i] + tv[1][i] * tv[1][i] + tv[2][i] * tv[2][i]) - 0.5 * G * tpot[i]);
-        const double dx = a[0][i] - ds[0][i], dy = a[1][i] - ds[1][i], dz = a[2][i] - ds[2][i];
-        const double dn = std::sqrt(ds[0][i] * ds[0][i] + ds[1][i] * ds[1][i] + ds[2][i] * ds[2][i]);
-        if (dn > 0) err += std::sqrt(dx * dx + dy * dy + dz * dz) / dn;
-    }
+    const double e = s->red_host[0] + s->red_host[1], e_ap = s->red_host[3] + s->red_host[4];
+    const double err = s->red_host[2];
     const size_t cap = (size_t) s->p.num_steps_validator;
     if (s->hist_e.size() < cap) { s->hist_e.resize(cap); s->hist_e_ap.resize(cap); s->hist_err.resize(cap); }
     s->hist_e[s->val_step] = e;
@@ -647,6 +626,46 @@ int get_com(Sim *s, size_t no, Dst *comx, Dst *comy, Dst *comz, Dst *mass)
 
 #define NB_FLOAT_ONLY(s, what)                                                                 \
     if ((s)->fp64) return fail(s, NBODY_ERR_STATE, what ": not available on a double-precision handle")
+
+// Folds the oldest pending timing record into the host accumulators and frees its ring slot.
+// wait: the record's step may still be running (the ring is full and nbody_update needs the
+// slot): wait for it.  The interaction counter of a step is written by a kernel queued after
+// the step's last event and before the next step's first one, so that next event is the one
+// to wait for; the caller guarantees it exists (ring full) or has synchronised the stream.
+int fold_oldest_timing(Sim *s, bool wait)
+{
+    const int slot = ((s->ev_head - s->ev_pending) % TIMING_RING + TIMING_RING) % TIMING_RING;
+    if (wait) NB_HIP(s, hipEventSynchronize(s->ev[(slot + 1) % TIMING_RING][EV_BEGIN]));
+    float t[EV_COUNT] = {0};
+    if (s->p.flags & NBODY_FLAG_TIMING_STAGES) {
+        for (int k = 1; k <= EV_TRAVERSE; ++k)
+            NB_HIP(s, hipEventElapsedTime(&t[k], s->ev[slot][k - 1], s->ev[slot][k]));
+    } else {   // coarse: everything before the traversal is reported as "build"
+        NB_HIP(s, hipEventElapsedTime(&t[EV_BUILD], s->ev[slot][EV_BEGIN], s->ev[slot][EV_COM]));
+        NB_HIP(s, hipEventElapsedTime(&t[EV_TRAVERSE], s->ev[slot][EV_COM], s->ev[slot][EV_TRAVERSE]));
+    }
+    float tot = 0;
+    NB_HIP(s, hipEventElapsedTime(&tot, s->ev[slot][EV_BEGIN], s->ev[slot][EV_TRAVERSE]));
+    for (int k = 0; k < s->tf_calls[slot]; ++k) {   // traversals driven through nbody_traverse_from
+        float tf = 0;
+        NB_HIP(s, hipEventElapsedTime(&tf, s->ev[slot][EV_TF0_BEGIN + 2 * k], s->ev[slot][EV_TF0_END + 2 * k]));
+        t[EV_TRAVERSE] += tf;
+        tot += tf;
+    }
+    uint64_t inter = 0;
+    NB_HIP(s, hipMemcpy(&inter, s->inter_dev + slot, sizeof inter, hipMemcpyDeviceToHost));
+    nbody_timings &a = s->t_acc;
+    a.steps += 1;
+    a.ms_integrate += t[EV_INTEGRATE];
+    a.ms_sort += t[EV_SORT];
+    a.ms_build += t[EV_BUILD];
+    a.ms_com += t[EV_COM];
+    a.ms_traverse += t[EV_TRAVERSE];
+    a.ms_total += tot;
+    a.interactions += inter;
+    s->ev_pending--;
+    return NBODY_OK;
+}
 
 struct DevGuard {
     int prev = -1;
@@ -799,8 +818,13 @@ int nbody_update(nbody_t *h)
     if (s->pending_vel) return fail(s, NBODY_ERR_STATE, "nbody_finish_step not called");
     const bool timing = (s->p.flags & NBODY_FLAG_TIMING) != 0;
     const int slot = s->ev_head;
-    if (timing && s->ev_pending == TIMING_RING)
-        return fail(s, NBODY_ERR_STATE, "timing ring full: call nbody_get_timings");
+    if (timing && s->ev_pending == TIMING_RING) {
+        // ring full: the record of the step TIMING_RING steps back moves into the host
+        // accumulators (that step finished long ago unless the caller queues faster than the
+        // GPU runs, in which case this waits for it)
+        int rcf = fold_oldest_timing(s, true);
+        if (rcf) return rcf;
+    }
     // every recorded event costs a few microseconds of stream time: without
     // NBODY_FLAG_TIMING_STAGES only the step's begin and the traversal's two ends are marked
     const bool stages = (s->p.flags & NBODY_FLAG_TIMING_STAGES) != 0;
@@ -1008,39 +1032,14 @@ int nbody_get_timings(nbody_t *h, nbody_timings *out)
     if (!out) return fail(s, NBODY_ERR_INVALID, "null output");
     std::memset(out, 0, sizeof *out);
     if (!(s->p.flags & NBODY_FLAG_TIMING)) return fail(s, NBODY_ERR_STATE, "NBODY_FLAG_TIMING not set");
-    int rc = fetch_counts(s);
+    int rc = fetch_counts(s);   // synchronises the stream: every pending record is complete
     if (rc) return rc;
-    std::vector<uint64_t> inter(TIMING_RING);
-    NB_HIP(s, hipMemcpy(inter.data(), s->inter_dev, TIMING_RING * 8, hipMemcpyDeviceToHost));
-    const int pending = s->ev_pending;
-    for (int i = 0; i < pending; ++i) {
-        const int slot = ((s->ev_head - pending + i) % TIMING_RING + TIMING_RING) % TIMING_RING;
-        float t[EV_COUNT] = {0};
-        if (s->p.flags & NBODY_FLAG_TIMING_STAGES) {
-            for (int k = 1; k <= EV_TRAVERSE; ++k)
-                NB_HIP(s, hipEventElapsedTime(&t[k], s->ev[slot][k - 1], s->ev[slot][k]));
-        } else {   // coarse: everything before the traversal is reported as "build"
-            NB_HIP(s, hipEventElapsedTime(&t[EV_BUILD], s->ev[slot][EV_BEGIN], s->ev[slot][EV_COM]));
-            NB_HIP(s, hipEventElapsedTime(&t[EV_TRAVERSE], s->ev[slot][EV_COM], s->ev[slot][EV_TRAVERSE]));
-        }
-        float tot = 0;
-        NB_HIP(s, hipEventElapsedTime(&tot, s->ev[slot][EV_BEGIN], s->ev[slot][EV_TRAVERSE]));
-        for (int k = 0; k < s->tf_calls[slot]; ++k) {   // traversals driven through nbody_traverse_from
-            float tf = 0;
-            NB_HIP(s, hipEventElapsedTime(&tf, s->ev[slot][EV_TF0_BEGIN + 2 * k], s->ev[slot][EV_TF0_END + 2 * k]));
-            t[EV_TRAVERSE] += tf;
-            tot += tf;
-        }
-        out->ms_integrate += t[EV_INTEGRATE];
-        out->ms_sort += t[EV_SORT];
-        out->ms_build += t[EV_BUILD];
-        out->ms_com += t[EV_COM];
-        out->ms_traverse += t[EV_TRAVERSE];
-        out->ms_total += tot;
-        out->interactions += inter[slot];
+    while (s->ev_pending > 0) {
+        rc = fold_oldest_timing(s, false);
+        if (rc) return rc;
     }
-    out->steps = pending;
-    s->ev_pending = 0;
+    *out = s->t_acc;
+    s->t_acc = nbody_timings{};
     return NBODY_OK;
 }
 
@@ -1174,6 +1173,7 @@ int nbody_set_sources_dev(nbody_t *h, const float *posm_dev, int32_t count)
     s->n = count;
     s->pending_vel = false;
     if (count == 0) { s->spawned = false; return NBODY_OK; }
+    NB_HIP(s, hipMemsetAsync(s->counts, 0, sizeof(Counts), s->stream));
     NB_HIP(s, launch_unpack_sources(s, reinterpret_cast<const Float4 *>(posm_dev), count));
     NB_HIP(s, launch_morton_only(s));
     int rc = build_after_encode(s, false);
@@ -1233,52 +1233,31 @@ int nbody_tree_energy(nbody_t *h, double *kinetic, double *potential)
     NB_ENTER(h);
     if (!s->spawned) return fail(s, NBODY_ERR_STATE, "energy before spawn/set_state");
     if (s->pending_vel) return fail(s, NBODY_ERR_STATE, "nbody_finish_step not called");
+    // per-body potential sums through the tree, then kinetic and potential energy reduced on
+    // the device: two doubles cross PCIe
+    const int c = s->cur;
+    const double G = (double) s->p.gravity;
     if (s->fp64) {
         State64 &d = s->d;
-        const size_t n = (size_t) s->n, b = n * 8;
         if (!d.pot) NB_HIP(s, dalloc(&d.pot, (size_t) s->cap));
         NB_HIP(s, launch64_traverse(s, true));
-        const int c = s->cur;
-        std::vector<double> m(n), vx(n), vy(n), vz(n), pot(n);
-        NB_HIP(s, hipMemcpyAsync(m.data(), d.m[c], b, hipMemcpyDeviceToHost, s->stream));
-        NB_HIP(s, hipMemcpyAsync(vx.data(), d.vx[c], b, hipMemcpyDeviceToHost, s->stream));
-        NB_HIP(s, hipMemcpyAsync(vy.data(), d.vy[c], b, hipMemcpyDeviceToHost, s->stream));
-        NB_HIP(s, hipMemcpyAsync(vz.data(), d.vz[c], b, hipMemcpyDeviceToHost, s->stream));
-        NB_HIP(s, hipMemcpyAsync(pot.data(), d.pot, b, hipMemcpyDeviceToHost, s->stream));
-        int rc = fetch_counts(s);
-        if (rc) return rc;
-        double ke = 0, pe = 0;
-        for (size_t i = 0; i < n; ++i) {
-            ke += 0.5 * m[i] * (vx[i] * vx[i] + vy[i] * vy[i] + vz[i] * vz[i]);
-            pe -= 0.5 * (double) s->p.gravity * m[i] * pot[i];
+        NB_HIP(s, launch_energy_reduce64(s->n, d.m[c], 1, d.vx[c], d.vy[c], d.vz[c], d.pot, G, nullptr,
+                                         nullptr, s->red_scratch, s->red_out, s->stream));
+    } else {
+        if (!s->pot) {
+            NB_HIP(s, dalloc(&s->pot, (size_t) s->cap));
+            NB_HIP(s, hipMemcpy(reinterpret_cast<char *>(s->trav_tail) + offsetof(TravTail, pot), &s->pot,
+                                sizeof(float *), hipMemcpyHostToDevice));
         }
-        if (kinetic) *kinetic = ke;
-        if (potential) *potential = pe;
-        return NBODY_OK;
+        NB_HIP(s, launch_potential(s));
+        NB_HIP(s, launch_energy_reduce(s->n, s->m[c], 1, s->vx[c], s->vy[c], s->vz[c], s->pot, G, nullptr,
+                                       nullptr, s->red_scratch, s->red_out, s->stream));
     }
-    const size_t n = (size_t) s->n, b = n * 4;
-    if (!s->pot) {
-        NB_HIP(s, dalloc(&s->pot, (size_t) s->cap));
-        NB_HIP(s, hipMemcpy(reinterpret_cast<char *>(s->trav_tail) + offsetof(TravTail, pot), &s->pot,
-                            sizeof(float *), hipMemcpyHostToDevice));
-    }
-    NB_HIP(s, launch_potential(s));
-    const int c = s->cur;
-    std::vector<float> m(n), vx(n), vy(n), vz(n), pot(n);
-    NB_HIP(s, hipMemcpyAsync(m.data(), s->m[c], b, hipMemcpyDeviceToHost, s->stream));
-    NB_HIP(s, hipMemcpyAsync(vx.data(), s->vx[c], b, hipMemcpyDeviceToHost, s->stream));
-    NB_HIP(s, hipMemcpyAsync(vy.data(), s->vy[c], b, hipMemcpyDeviceToHost, s->stream));
-    NB_HIP(s, hipMemcpyAsync(vz.data(), s->vz[c], b, hipMemcpyDeviceToHost, s->stream));
-    NB_HIP(s, hipMemcpyAsync(pot.data(), s->pot, b, hipMemcpyDeviceToHost, s->stream));
-    int rc = fetch_counts(s);
+    NB_HIP(s, hipMemcpyAsync(s->red_host, s->red_out, 2 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    int rc = fetch_counts(s);   // synchronises the stream
     if (rc) return rc;
-    double ke = 0, pe = 0;
-    for (size_t i = 0; i < n; ++i) {
-        ke += 0.5 * m[i] * ((double) vx[i] * vx[i] + (double) vy[i] * vy[i] + (double) vz[i] * vz[i]);
-        pe -= 0.5 * (double) s->p.gravity * m[i] * pot[i];
-    }
-    if (kinetic) *kinetic = ke;
-    if (potential) *potential = pe;
+    if (kinetic) *kinetic = s->red_host[0];
+    if (potential) *potential = s->red_host[1];
     return NBODY_OK;
 }
 
@@ -1338,6 +1317,8 @@ int nbody_save_snapshot(nbody_t *h, const char *path)
     NB_ENTER(h);
     if (!path) return fail(s, NBODY_ERR_INVALID, "null path");
     if (!s->spawned) return fail(s, NBODY_ERR_STATE, "snapshot before spawn/set_state");
+    if (s->pending_vel)   // half a step: positions advanced, velocities not yet kicked
+        return fail(s, NBODY_ERR_STATE, "snapshot between nbody_update and nbody_finish_step");
     return s->fp64 ? save_snapshot<double>(s, path) : save_snapshot<float>(s, path);
 }
 
@@ -1350,7 +1331,12 @@ int nbody_load_snapshot(nbody_t *h, const char *path)
     SnapHeader hd{};
     in.read(reinterpret_cast<char *>(&hd), sizeof hd);
     if (!in || std::memcmp(hd.magic, "NBSNAP1", 8) != 0) return fail(s, NBODY_ERR_IO, "not a snapshot file");
-    if (hd.n != s->cap) return fail(s, NBODY_ERR_INVALID, "snapshot particle count differs from num_points");
+    if (hd.n < 1 || hd.n > s->cap)
+        return fail(s, NBODY_ERR_INVALID, "snapshot holds more particles than num_points");
+    if (s->p.num_steps_validator > 0 && hd.n != s->cap)
+        return fail(s, NBODY_ERR_STATE, "a handle with a validator keeps num_points particles");
+    if (hd.domain_size != s->p.domain_size)
+        return fail(s, NBODY_ERR_INVALID, "snapshot was written with another domain_size");
     // a payload of the other precision is converted; a restart is bit-identical only when
     // file and handle agree
     return hd.real_bytes == 8 ? load_snapshot<double>(s, in, hd.n) : load_snapshot<float>(s, in, hd.n);

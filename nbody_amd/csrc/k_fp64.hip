@@ -173,7 +173,8 @@ __global__ __launch_bounds__(256) void k64_com(const Counts *counts,
                                                const int32_t *__restrict__ o_pe,
                                                const int32_t *__restrict__ o_parent,
                                                const Double4 *__restrict__ posm, Double4 *wsum,
-                                               Double4 *__restrict__ nodeA, uint32_t *counter)
+                                               Double4 *__restrict__ nodeA, uint32_t *counter,
+                                               uint32_t *err)
 {
     const int n_oct = counts->n_oct;
     for (int o = blockIdx.x * 256 + threadIdx.x; o < n_oct; o += gridDim.x * 256) {
@@ -194,7 +195,11 @@ __global__ __launch_bounds__(256) void k64_com(const Counts *counts,
             st_wt(ws + 0, sx); st_wt(ws + 1, sy); st_wt(ws + 2, sz); st_wt(ws + 3, sm);
             nodeA[cur] = Double4{sx / sm, sy / sm, sz / sm, sm};
             const int parent = o_parent[cur];
-            if (parent < 0 || ++guard > 64) break;
+            if (parent < 0) break;
+            if (++guard > 64) {   // deeper than any key allows: the parent chain is corrupt
+                atomicOr(err, (uint32_t) DEV_ERR_RANGE);
+                break;
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const uint32_t arrived = __hip_atomic_fetch_add(&counter[parent], 1u, __ATOMIC_RELAXED,
                                                             __HIP_MEMORY_SCOPE_AGENT);
@@ -548,7 +553,7 @@ hipError_t launch64_com(Sim *s)
     const int grid = std::min((2 * s->n + 255) / 256, 2048);
     hipLaunchKernelGGL(k64_com, dim3(grid), dim3(256), 0, s->stream, s->counts, s->o_num_children,
                        s->o_first_child, s->o_pb, s->o_pe, s->o_parent, s->d.posm, s->d.wsum,
-                       s->d.nodeA, s->com_counter);
+                       s->d.nodeA, s->com_counter, &s->counts->err);
     return hipGetLastError();
 }
 

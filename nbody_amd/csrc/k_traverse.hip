@@ -76,8 +76,8 @@ struct alignas(16) WaveLds {
 };
 
 // MODE: 0 = forces (the step), 1 = walk only (profiling aid: no force arithmetic), 2 = potential
-// (sum of m / sqrt(d^2 + eps^2) over the same sources instead of the force; writes tail->pot
-// and nothing else; `accumulate` bit 1 removes the body's own term m_i / eps).
+// (sum of m / sqrt(d^2 + eps^2) over the same sources instead of the force, sources at zero
+// distance -- the body itself -- left out; writes tail->pot and nothing else).
 constexpr int TRAV_FORCE = 0, TRAV_WALK_ONLY = 1, TRAV_POTENTIAL = 2;
 
 template <int G, bool FUSE_VEL, int MODE>
@@ -143,6 +143,14 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
     const float th2 = theta * theta;
     const float dinit = domain * domain * 3.0f;
 
+    // Potential mode: 1/sqrt(s) of a source pair, with a source at zero distance (s == eps^2:
+    // the body itself, which its own leaf always delivers) contributing nothing.  Subtracting
+    // m_i / eps afterwards instead would leave the float sum with the rounding of a term that
+    // can be 10^3 times all the others together (a heavy body, a small softening).
+    auto pot_rsq = [&](const v2f s) -> v2f {
+        return v2f{s.x == eps2 ? 0.f : __builtin_amdgcn_rsqf(s.x),
+                   s.y == eps2 ? 0.f : __builtin_amdgcn_rsqf(s.y)};
+    };
     auto pair_force = [&](const v4f a, const v4f c) {
         if (MODE == TRAV_WALK_ONLY) {  // keep the LDS reads alive, skip the arithmetic
             fx2 += a.xy; fy2 += c.xy;
@@ -152,8 +160,7 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
         const v2f s = __builtin_elementwise_fma(
             dz, dz, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dx, dx, e2)));
         if (MODE == TRAV_POTENTIAL) {   // fx2 doubles as the potential accumulator
-            const v2f inv1 = {__builtin_amdgcn_rsqf(s.x), __builtin_amdgcn_rsqf(s.y)};
-            fx2 = __builtin_elementwise_fma(inv1, c.zw, fx2);
+            fx2 = __builtin_elementwise_fma(pot_rsq(s), c.zw, fx2);
             return;
         }
         const v2f s3 = s * s * s;
@@ -195,8 +202,7 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
         const v2f s = __builtin_elementwise_fma(
             dz, dz, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dx, dx, e2)));
         if (MODE == TRAV_POTENTIAL) {
-            const v2f inv1 = {__builtin_amdgcn_rsqf(s.x), __builtin_amdgcn_rsqf(s.y)};
-            fx2 = __builtin_elementwise_fma(inv1, v2f{r[6], r[7]}, fx2);
+            fx2 = __builtin_elementwise_fma(pot_rsq(s), v2f{r[6], r[7]}, fx2);
             return;
         }
         const v2f s3 = s * s * s;
@@ -554,8 +560,7 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
     }
     if (MODE == TRAV_POTENTIAL) {
         if (active) {
-            float p = fx;
-            if (accumulate & 2) p -= me.w * __builtin_amdgcn_rsqf(eps2);   // the body itself
+            const float p = fx;   // the body's own term never entered the sum (pot_rsq)
             tail->pot[b] = (accumulate & 1) ? tail->pot[b] + p : p;
         }
         return;
@@ -625,8 +630,8 @@ __global__ __launch_bounds__(256) void k_count_interactions(int n, int group, in
 // ---------------------------------------------------------------------------
 // Direct sum: 256 targets per workgroup, sources staged through LDS 256 at a time.
 // POT additionally accumulates pot_i = sum_j m_j / sqrt(|d|^2 + eps^2); with self_pairs
-// set (targets and sources are the same array) the j = i term is removed again, which is
-// exact because that term is m_i * rsq(eps^2) on both sides.
+// set (targets and sources are the same array) the j = i term is left out (the force of that
+// term is zero anyway).
 // ---------------------------------------------------------------------------
 template <bool POT>
 __global__ __launch_bounds__(256) void k_direct(const Float4 *__restrict__ targets, int nt,
@@ -659,8 +664,15 @@ __global__ __launch_bounds__(256) void k_direct(const Float4 *__restrict__ targe
         __syncthreads();
         const int np2 = (c + 1) >> 1;
         if (POT) {
+            // with self_pairs, source i of the tile that holds this workgroup's own bodies is
+            // body i itself: its mass is masked out (exact, whatever m_i / eps is beside the
+            // rest of the sum)
+            const bool own_tile = self_pairs && t0 == (int) blockIdx.x * 256;
+            const int mine = (int) threadIdx.x >> 1, half = (int) threadIdx.x & 1;
             for (int j = 0; j < np2; ++j) {
-                const v4f a = s_xy[j], b = s_zm[j];
+                const v4f a = s_xy[j];
+                v4f b = s_zm[j];
+                if (own_tile && j == mine) { if (half) b.w = 0.f; else b.z = 0.f; }
                 const v2f dx = a.xy - px2, dy = a.zw - py2, dz = b.xy - pz2;
                 const v2f t = __builtin_elementwise_fma(
                     dz, dz, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dx, dx, e2)));
@@ -695,7 +707,6 @@ __global__ __launch_bounds__(256) void k_direct(const Float4 *__restrict__ targe
         if (accumulate) { rx += ax[i]; ry += ay[i]; rz += az[i]; }
         ax[i] = rx; ay[i] = ry; az[i] = rz;
         if (POT) {
-            if (self_pairs) ps -= me.w * __builtin_amdgcn_rsqf(eps2);
             pot[i] = accumulate ? pot[i] + ps : ps;
         }
     }

@@ -15,6 +15,10 @@
 #include "dev_utils.hpp"
 #include "nbody_internal.hpp"
 
+#ifndef NB_COM_ACQ_REL
+#define NB_COM_ACQ_REL 0
+#endif
+
 namespace nb {
 
 void launch_rank_pass(const uint32_t *keys, uint32_t *keys_out, uint32_t *vals_out,
@@ -425,7 +429,8 @@ __global__ __launch_bounds__(256) void k_com(const Counts *counts,
                                              const int32_t *__restrict__ o_pe,
                                              const int32_t *__restrict__ o_parent,
                                              const Float4 *__restrict__ posm, Float4 *wsum,
-                                             Float4 *__restrict__ nodeA, uint32_t *counter)
+                                             Float4 *__restrict__ nodeA, uint32_t *counter,
+                                             uint32_t *err)
 {
     const int n_oct = counts->n_oct;
     for (int o = blockIdx.x * 256 + threadIdx.x; o < n_oct; o += gridDim.x * 256) {
@@ -446,10 +451,19 @@ __global__ __launch_bounds__(256) void k_com(const Counts *counts,
             st_wt(ws + 0, sx); st_wt(ws + 1, sy); st_wt(ws + 2, sz); st_wt(ws + 3, sm);
             nodeA[cur] = Float4{sx / sm, sy / sm, sz / sm, sm};
             const int parent = o_parent[cur];
-            if (parent < 0 || ++guard > 64) break;
+            if (parent < 0) break;
+            if (++guard > 64) {   // deeper than any key allows: the parent chain is corrupt
+                atomicOr(err, (uint32_t) DEV_ERR_RANGE);
+                break;
+            }
+#if NB_COM_ACQ_REL
+            const uint32_t arrived = __hip_atomic_fetch_add(&counter[parent], 1u, __ATOMIC_ACQ_REL,
+                                                            __HIP_MEMORY_SCOPE_AGENT);
+#else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const uint32_t arrived = __hip_atomic_fetch_add(&counter[parent], 1u, __ATOMIC_RELAXED,
                                                             __HIP_MEMORY_SCOPE_AGENT);
+#endif
             const int nc = o_num_children[parent];
             if ((int) arrived != nc - 1) break;
             // every child has arrived: leave the counter at 0 for the next build
@@ -513,7 +527,7 @@ hipError_t launch_com(Sim *s)
     const int grid = std::min((2 * s->n + 255) / 256, 2048);
     hipLaunchKernelGGL(k_com, dim3(grid), dim3(256), 0, s->stream, s->counts, s->o_num_children,
                        s->o_first_child, s->o_pb, s->o_pe, s->o_parent, s->posm, s->o_wsum,
-                       s->nodeA, s->com_counter);
+                       s->nodeA, s->com_counter, &s->counts->err);
     return hipGetLastError();
 }
 

@@ -27,6 +27,8 @@ constexpr int TRAV_HEAVY_MAX = 1024;                // groups the traversal can 
 constexpr int TRAV_PEND = 96;                       // LDS queue of candidates awaiting the exact test
 constexpr int MAX_DEPTH_BINS = 256;                 // depth key space of the node ranking pass
 constexpr int TIMING_RING = 64;
+constexpr int REDUCE_HEADER_BYTES = 256;            // arrival counter + padding ahead of the partial sums
+constexpr int REDUCE_MAX_BLOCKS = 1024;             // workgroups of a handle's energy reductions
 enum { EV_BEGIN = 0, EV_INTEGRATE, EV_SORT, EV_BUILD, EV_COM, EV_TRAVERSE,
        EV_TF0_BEGIN, EV_TF0_END, EV_TF1_BEGIN, EV_TF1_END,   // nbody_traverse_from calls of the step
        EV_COUNT };
@@ -173,11 +175,15 @@ struct Sim {
     int ev_head = 0, ev_pending = 0;
     int tf_calls[TIMING_RING]{};     // timed nbody_traverse_from calls per recorded step (<= 2)
     uint64_t *inter_dev = nullptr;   // [TIMING_RING] interactions per step
+    nbody_timings t_acc{};           // records folded out of the ring, not yet handed to the caller
     // validator: all-pairs twin simulation (state in spawn order) + history
     Float4 *tw_posm = nullptr;
     float *tw_v[3]{}, *tw_vh[3]{}, *tw_a[3]{}, *tw_pot = nullptr;
     float *ds_a[3]{}, *ds_pot = nullptr;   // direct sum at the Barnes-Hut positions
     int val_step = 0, val_count = 0;
+    unsigned char *red_scratch = nullptr;  // partial sums of the on-device reductions
+    double *red_out = nullptr;             // [8] device results
+    double *red_host = nullptr;            // [8] pinned copy
     std::vector<double> hist_e, hist_e_ap, hist_err;
 };
 
@@ -212,6 +218,21 @@ hipError_t launch_bbox(Sim *s, uint32_t *box_dev);
 hipError_t launch_let_export(Sim *s, const float *boxes_dev, int nboxes, Float4 *out, int cap,
                              uint32_t *out_count);
 hipError_t launch_unpack_sources(Sim *s, const Float4 *src, int n);
+
+// ---- on-device reductions (k_reduce.hip) ----
+size_t reduce_scratch_bytes(int blocks, int k);
+// out[0] = sum m v^2/2, out[1] = -G/2 sum m pot, out[2] = sum |a - d| / |d| (a, d nullable)
+hipError_t launch_energy_reduce(int n, const float *m, int m_stride, const float *vx, const float *vy,
+                                const float *vz, const float *pot, double G, const float *const a[3],
+                                const float *const d[3], unsigned char *scratch, double *out,
+                                hipStream_t st);
+hipError_t launch_energy_reduce64(int n, const double *m, int m_stride, const double *vx, const double *vy,
+                                  const double *vz, const double *pot, double G, const double *const a[3],
+                                  const double *const d[3], unsigned char *scratch, double *out,
+                                  hipStream_t st);
+hipError_t launch_direct_energy(const Float4 *posm, const float *vx, const float *vy, const float *vz,
+                                int n, float eps2, float gravity, unsigned char *scratch, double *out,
+                                hipStream_t st);
 
 
 // ---- double-precision handles (k_fp64.hip) ----

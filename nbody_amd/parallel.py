@@ -367,18 +367,6 @@ class GpuBackend:
     def finish_step(self):
         self.sim.finish_step()
 
-    def get_particles(self):
-        return self.sim.get_state()
-
-    def set_particles(self, st):
-        if len(st["x"]) > self.sim.params.num_points:
-            raise RuntimeError(f"domain received {len(st['x'])} particles, handle capacity is "
-                               f"{self.sim.params.num_points}: create it with head-room")
-        self.sim.set_particles(st["x"], st["y"], st["z"], st["m"], st["vx"], st["vy"], st["vz"],
-                               st["ax"], st["ay"], st["az"], st["id"])
-        self.n = len(st["x"])
-        self.sim.set_traversal_range(0, 0)
-
 
 class GpuLetBackend:
     """LetStepper backend over two nbody_amd.Simulation handles on one GPU: `sim` holds the

@@ -58,7 +58,8 @@ def test_sampler_distributions():
     assert rp.max() <= 1.0 + 1e-5 and abs(np.median(rp) - 0.1 * 1.3048) < 0.01
     assert np.isclose(pl["m"].sum(), 1.0, rtol=1e-4)
     # reproducible and seed dependent
-    assert np.array_equal(nb.sample_ic(nb.IC_DISK, 100, 42)["x"], d["x"][:100]) is False or True
+    # counter-based: particle i's draws depend on (seed, i) only, not on how many are sampled
+    assert np.array_equal(nb.sample_ic(nb.IC_DISK, 100, 42)["x"], d["x"][:100])
     assert np.array_equal(nb.sample_ic(nb.IC_DISK, 20000, 42)["x"], d["x"])
     assert not np.array_equal(nb.sample_ic(nb.IC_DISK, 20000, 43)["x"], d["x"])
 
@@ -75,9 +76,10 @@ def test_invalid_params_rejected():
 
 
 def test_no_cpu_fallback_without_gpu():
+    import pytest
     import torch
     if torch.cuda.is_available():
-        return
+        pytest.skip("a GPU is present: the failure path of a GPU-less host cannot be exercised")
     try:
         nb.Simulation(nb.Params(num_points=1024))
     except RuntimeError as e:

@@ -78,7 +78,29 @@ def test_energy_drift_1000_steps_32k_disk():
     # spawn doing no force evaluation (first kick with a = 0, as in the reference)
     assert np.abs((e - e[0]) / e[0]).max() < 1e-2       # drift of the tree run
     assert np.abs((ea - ea[0]) / ea[0]).max() < 1e-2    # drift of the all-pairs run
-    assert err.mean() < 8e-4 and err.max() < 2e-3       # published theta = 0.5 band
+    assert 3e-4 < err.mean() < 8e-4 and err.max() < 2e-3   # published theta = 0.5 band (two-sided)
+    # Energy LEVEL.  The published all-pairs curve sits at -82.39; the shipped sampler gives
+    # -77.9 at this eps = 0.01 before the first step (see test_disk_initial_energy_analytic_and_
+    # published in test_oracle.py: -82.39 belongs to eps <= 1e-3), and the first step, whose
+    # kick-drift runs with a = 0 (exec_post_spawn does no force evaluation), lifts it once by
+    # ~3 % to -75.5; from there both runs are flat.
+    assert abs(ea[0] + 75.47) < 0.3 and abs(ea[100:].mean() + 75.5) < 0.5, (ea[0], ea[100:].mean())
+
+
+def test_disk_energy_level_at_renderer_softening_matches_published_plot():
+    """The level of the reference's energy plot (-82.39, plots/disk-energy-32k-eps0.01-dt0.001.png)
+    against the energy of the spawned 32,768-particle disk evaluated on the GPU (all pairs:
+    theta = 0 sends every particle to every group) at the renderer's disk softening 1e-3
+    (src/renderer.cpp:311): within 1 %."""
+    n = 32768
+    p = nb.Params(num_points=n, morton_bits=21, theta=0.0, dt=1e-3, softening_factor=1e-3)
+    with nb.Simulation(p) as sim:
+        sim.spawn_disk()
+        ke, pe = sim.tree_energy()
+        st = sim.get_state()
+    e_ref = O.energy_f64(st["x"], st["y"], st["z"], st["vx"], st["vy"], st["vz"], st["m"], 1e-3, 1.0)
+    assert abs((ke + pe) - e_ref) < 2e-4 * abs(e_ref), (ke + pe, e_ref)
+    assert abs((ke + pe) + 82.39) / 82.39 < 0.01, ke + pe
 
 
 @pytest.mark.parametrize("theta,rtol", [(0.0, 5e-5), (0.5, 2e-3)])   # float32 per-body sums
@@ -102,3 +124,31 @@ def test_tree_energy_matches_all_pairs_energy(theta, rtol):
     e_ref = O.energy_f64(st["x"], st["y"], st["z"], st["vx"], st["vy"], st["vz"], st["m"], 0.01, 1.0)
     assert abs(ke - ke_ref) <= 1e-12 * abs(ke_ref)
     assert abs((ke + pe) - e_ref) <= rtol * abs(e_ref), (ke + pe, e_ref)
+
+
+@pytest.mark.parametrize("kind,n,eps", [(nb.IC_DISK, 20000, 0.01), (nb.IC_PLUMMER, 4097, 0.02),
+                                        (nb.IC_SPHERE, 1, 0.1), (nb.IC_DISK, 255, 1e-3)])
+def test_direct_energy_on_device_matches_oracle(kind, n, eps):
+    """nbody_direct_energy_dev: kinetic and all-pairs potential energy reduced on the GPU (the
+    reference's compute_conserved_quantities + cub::DeviceReduce::Sum) against the oracle's
+    float64 energy.  Kinetic is a double sum of float products (1e-12); the per-body potential
+    sums are float32 (1e-4 of the total, the star's term dominating the disk's)."""
+    import torch
+    ic = nb.sample_ic(kind, n, 9, p0=0.1, p1=1.0)
+    posm = torch.from_numpy(np.stack([ic["x"], ic["y"], ic["z"], ic["m"]], 1).astype(np.float32)).cuda()
+    v = [torch.from_numpy(ic[k]).cuda() for k in ("vx", "vy", "vz")]
+    out = torch.full((2,), np.nan, dtype=torch.float64, device="cuda")
+    lib = nb.load_library()
+    for _ in range(2):     # twice: the scratch counter is left ready for the next call
+        rc = lib.nbody_direct_energy_dev(posm.data_ptr(), v[0].data_ptr(), v[1].data_ptr(), v[2].data_ptr(),
+                                         n, eps, 1.0, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        ke, pe = out.cpu().numpy()
+        m = ic["m"].astype(np.float64)
+        ke_ref = float(np.sum(0.5 * m * (ic["vx"].astype(np.float64) ** 2 + ic["vy"].astype(np.float64) ** 2 +
+                                         ic["vz"].astype(np.float64) ** 2)))
+        e_ref = O.energy_f64(ic["x"], ic["y"], ic["z"], ic["vx"], ic["vy"], ic["vz"], ic["m"], eps, 1.0)
+        assert abs(ke - ke_ref) <= 1e-12 * abs(ke_ref) + 1e-300
+        assert abs((ke + pe) - e_ref) <= 1e-4 * max(abs(e_ref), abs(pe)) + 1e-300, (ke + pe, e_ref)
+    assert lib.nbody_direct_energy_dev(posm.data_ptr(), v[0].data_ptr(), v[1].data_ptr(), v[2].data_ptr(),
+                                       0, eps, 1.0, out.data_ptr(), None) == 1
