@@ -299,6 +299,19 @@ int nbody_direct_energy_dev(const float *posm, const float *vx, const float *vy,
                             int32_t n, float softening_factor, float gravity, double *out_dev,
                             void *stream);
 
+/* nbody_direct_energy_dev for callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the
+ * reference.  Same arguments, same kernel and the same result, bit for bit; the partial sums
+ * live in a fixed array in device memory (256 KiB + 256 B per GPU, held until the process
+ * ends) instead of a buffer allocated per call, so the call allocates and frees nothing,
+ * does not synchronise, and is limited to n <= 4,194,304 (NBODY_ERR_CAPACITY beyond that: use
+ * nbody_direct_energy_dev).  The stream's device must be current.  All calls on one GPU share
+ * that GPU's array: calls that overlap in time on one GPU (different streams, different
+ * threads) race; calls on one stream, or otherwise ordered, are safe. */
+int nbody_direct_energy_dev_noalloc(const float *posm, const float *vx, const float *vy,
+                                    const float *vz, int32_t n, float softening_factor,
+                                    float gravity, double *out_dev, void *stream);
+
 /* Multi-GPU sharded traversal: restrict nbody_update()'s traversal to groups
  * [group_begin, group_end) of the sorted order; the caller (one process per GPU) then
  * exchanges the accelerations (nbody_dev_view.ax/ay/az slices) with an all-gather and

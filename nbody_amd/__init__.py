@@ -87,7 +87,7 @@ EXPORTS = [
     "nbody_traverse_from", "nbody_save_snapshot", "nbody_load_snapshot", "nbody_set_particles",
     "nbody_tree_energy", "nbody_set_state_f64", "nbody_get_state_f64", "nbody_sample_ic_f64",
     "nbody_get_octree_com_f64", "nbody_direct_sum_f64", "nbody_get_device_ptrs_f64",
-    "nbody_direct_energy_dev",
+    "nbody_direct_energy_dev", "nbody_direct_energy_dev_noalloc",
 ]
 
 _lib = None
@@ -161,6 +161,7 @@ def load_library() -> C.CDLL:
     lib.nbody_get_device_ptrs_f64.argtypes = [C.c_void_p, C.POINTER(CDevView)]
     lib.nbody_direct_energy_dev.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_float, C.c_float,
                                                               C.c_void_p, C.c_void_p]
+    lib.nbody_direct_energy_dev_noalloc.argtypes = lib.nbody_direct_energy_dev.argtypes
     _lib = lib
     return lib
 

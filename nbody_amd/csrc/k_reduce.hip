@@ -213,7 +213,41 @@ hipError_t launch_direct_energy(const Float4 *posm, const float *vx, const float
 // ---------------------------------------------------------------------------
 // Stateless C-ABI entry points: total energy of a particle set by direct summation.
 // ---------------------------------------------------------------------------
+#include <mutex>
+
 namespace {
+
+constexpr int NOALLOC_MAX_BODIES = 4194304;
+constexpr int NOALLOC_MAX_BLOCKS = NOALLOC_MAX_BODIES / 256;
+constexpr int NOALLOC_MAX_DEVICES = 64;
+
+// Scratch of nbody_direct_energy_dev_noalloc: arrival counter + one (kinetic, potential)
+// partial per workgroup.  Every GPU the library runs on holds its own copy of this array for
+// the life of the process; host code reaches it only through the address hipGetSymbolAddress
+// returns for the current device (the name below is not a device address).
+static __device__ __align__(256) unsigned char scratch[nb::REDUCE_HEADER_BYTES + NOALLOC_MAX_BLOCKS * 2 * sizeof(double)];
+
+std::mutex g_scratch_mutex;
+unsigned char *g_scratch_ptr[NOALLOC_MAX_DEVICES] = {};
+
+// Address of the current device's copy of `scratch` (looked up once per device).
+hipError_t scratch_for_current_device(unsigned char **out)
+{
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= NOALLOC_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void *ptr = nullptr;
+        e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!ptr) return hipErrorInvalidSymbol;
+        g_scratch_ptr[dev] = static_cast<unsigned char *>(ptr);
+    }
+    *out = g_scratch_ptr[dev];
+    return hipSuccess;
+}
 
 bool energy_args_ok(const float *posm, const float *vx, const float *vy, const float *vz, int32_t n,
                     float softening_factor, double *out_dev)
@@ -240,6 +274,27 @@ int nbody_direct_energy_dev(const float *posm, const float *vx, const float *vy,
                                      softening_factor * softening_factor, gravity, buf, out_dev, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);   // the scratch is freed below
     (void) hipFree(buf);
+    return e == hipSuccess ? NBODY_OK : NBODY_ERR_HIP;
+}
+
+int nbody_direct_energy_dev_noalloc(const float *posm, const float *vx, const float *vy,
+                                    const float *vz, int32_t n, float softening_factor,
+                                    float gravity, double *out_dev, void *stream)
+{
+    if (!energy_args_ok(posm, vx, vy, vz, n, softening_factor, out_dev)) return NBODY_ERR_INVALID;
+    if (n > NOALLOC_MAX_BODIES) {
+        fprintf(stderr, "nbody_direct_energy_dev_noalloc: %d bodies exceed the fixed scratch (max %d); "
+                        "use nbody_direct_energy_dev\n", n, NOALLOC_MAX_BODIES);
+        return NBODY_ERR_CAPACITY;
+    }
+    unsigned char *ptr = nullptr;
+    if (scratch_for_current_device(&ptr) != hipSuccess) return NBODY_ERR_HIP;
+    hipStream_t st = (hipStream_t) stream;
+    // the arrival counter must start at zero whatever an earlier, possibly failed, call left
+    hipError_t e = hipMemsetAsync(ptr, 0, nb::REDUCE_HEADER_BYTES, st);
+    if (e == hipSuccess)
+        e = nb::launch_direct_energy(reinterpret_cast<const nb::Float4 *>(posm), vx, vy, vz, n,
+                                     softening_factor * softening_factor, gravity, ptr, out_dev, st);
     return e == hipSuccess ? NBODY_OK : NBODY_ERR_HIP;
 }
 
