@@ -12,10 +12,12 @@ input is resident in HBM when timing starts.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): weak scaling with
 2,097,152 particles per GPU, i.e. one sphere of N x 2,097,152 particles.
-  --parallelism let (default): domain decomposition.  Every rank owns one box of an
-      orthogonal recursive bisection, builds and traverses its own tree, and imports a
-      locally-essential tree from the others (all-gather of boxes + one all-to-all of
-      (x,y,z,m) records per step).
+  --parallelism let (default): domain decomposition along the Morton curve (nbody_dd_*).
+      Every rank samples its own slice of the initial conditions, the ranks agree on
+      Morton-key ranges of equal particle count (all-gathered key histograms) and migrate
+      the particles; per step every rank builds and traverses the tree of its own range and
+      imports a locally-essential tree from the others (all-gather of the top-of-tree
+      nodes + one all-to-all of (x,y,z,m) records).  No rank ever holds the whole set.
   --parallelism replicated: every rank holds the whole particle set and builds the same
       tree; the traversal is sharded by Morton-contiguous group ranges and the
       accelerations are exchanged with one all-gather per step (bit-identical to 1 GPU).
@@ -212,33 +214,37 @@ def main():
     ngroups = (n + group - 1) // group
     let = world > 1 and args.parallelism == "let"
     eps = EPS
+    kind, p0, p1 = nb.IC_SPHERE, 0.0, 0.0
     if args.ic == "plummer":
-        ic = nb.sample_ic(nb.IC_PLUMMER, n, 42, p0=0.1, p1=1.0)
+        kind, p0, p1 = nb.IC_PLUMMER, 0.1, 1.0
         eps = 1e-3
-    else:
-        ic = nb.sample_ic(nb.IC_SPHERE, n, 42)
-    if let:
-        from nbody_amd import parallel
-        own = parallel.domain_slices(ic["x"], ic["y"], ic["z"], world, grid=(5.0, args.morton_bits))[rank]
-        ic = {k: v[own] for k, v in ic.items()}
-    else:
-        assert ngroups % world == 0, "groups must divide evenly over the ranks"
-    n_here = len(ic["x"])
-    params = nb.Params(num_points=n_here, max_num_codes_per_leaf=32, traversal_group_size=group,
-                       theta=THETA, dt=DT, gravity=1.0, softening_factor=eps, domain_size=5.0,
-                       morton_bits=args.morton_bits, device_id=local_rank,
-                       flags=nb.FLAG_TIMING | (nb.FLAG_DEBUG_WALK_ONLY if args.walk_only else 0))
-    sim = nb.Simulation(params)
-    sim.set_state(ic["x"], ic["y"], ic["z"], ic["m"])
-    U, M, n_oct = sim.tree_counts()
-
+    flags = nb.FLAG_TIMING | (nb.FLAG_DEBUG_WALK_ONLY if args.walk_only else 0)
+    ic = None
     stepper = None
     if let:
-        stepper = parallel.LetStepper(parallel.GpuLetBackend(
-            sim, f"cuda:{local_rank}", exchange_device="cpu" if rehearse else None))
-    elif world > 1:
         from nbody_amd import parallel
-        stepper = parallel.ShardedTraversal(parallel.GpuBackend(sim, f"cuda:{local_rank}"))
+        # head-room: equal-count key ranges hold n / world particles each, within 1 %
+        cap = int(args.particles_per_gpu * 1.25) + 4096
+        params = nb.Params(num_points=cap, max_num_codes_per_leaf=32, traversal_group_size=group,
+                           theta=THETA, dt=DT, gravity=1.0, softening_factor=eps, domain_size=5.0,
+                           morton_bits=args.morton_bits, device_id=local_rank, flags=flags)
+        sim = nb.Simulation(params)
+        stepper = parallel.DomainDecomposition(sim, f"cuda:{local_rank}", via_host=rehearse)
+        stepper.spawn(kind, n, p0, p1)      # own slice of the set, then key ranges + migration
+        n_here = stepper.stats()["n_local"]
+    else:
+        ic = nb.sample_ic(kind, n, 42, p0=p0, p1=p1)
+        assert ngroups % world == 0, "groups must divide evenly over the ranks"
+        n_here = len(ic["x"])
+        params = nb.Params(num_points=n_here, max_num_codes_per_leaf=32, traversal_group_size=group,
+                           theta=THETA, dt=DT, gravity=1.0, softening_factor=eps, domain_size=5.0,
+                           morton_bits=args.morton_bits, device_id=local_rank, flags=flags)
+        sim = nb.Simulation(params)
+        sim.set_state(ic["x"], ic["y"], ic["z"], ic["m"])
+        if world > 1:
+            from nbody_amd import parallel
+            stepper = parallel.ShardedTraversal(parallel.GpuBackend(sim, f"cuda:{local_rank}"))
+    U, M, n_oct = sim.tree_counts()
 
     def one_step():
         if stepper is None:
@@ -264,10 +270,6 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step()
-        if (i + 1) % 48 == 0 and i + 1 < args.steps:  # event ring holds 64 steps
-            t = sim.get_timings()
-            for k in tim:
-                tim[k] += t[k]
     fence()
     elapsed = time.perf_counter() - t0
     t = sim.get_timings()
@@ -287,12 +289,8 @@ def main():
     e_start = sum(sim.tree_energy()) if world == 1 and not args.walk_only else None
     evolved = None
     if world == 1 and args.evolve_steps > 0 and not args.walk_only:
-        left = args.evolve_steps
-        while left > 0:
-            k = min(left, 48)
-            sim.step(k)
-            sim.get_timings()
-            left -= k
+        sim.step(args.evolve_steps)
+        sim.get_timings()
         sim.sync()
         ta = time.perf_counter()
         sim.step(20)
@@ -312,6 +310,9 @@ def main():
         evolved["energy"] = {"after_timed_region": e_start, "after_collapse": e_end,
                              "relative_change": round((e_end - e_start) / abs(e_start), 6),
                              "note": "kinetic + tree potential (nbody_tree_energy)"}
+    let_stats = stepper.stats() if let else None
+    if let:
+        stepper.close()
     sim.close()
 
     stage = None
@@ -418,7 +419,8 @@ def main():
                                    "dt=1e-6, 32 codes/leaf, group=64",
                        "particles": n, "morton_bits": args.morton_bits,
                        "parallelism": "single" if world == 1 else
-                       (f"{world} domains (orthogonal recursive bisection), own tree per GPU, "
+                       (f"{world} Morton-key ranges of equal particle count (all-gathered key "
+                        "histograms), own tree per GPU, all-gather of top-of-tree nodes, "
                         "locally-essential-tree exchange (all-to-all of records)" if let else
                         f"replicated build, traversal sharded over {world} Morton ranges, "
                         "all-gather of accelerations"),
@@ -461,8 +463,11 @@ def main():
             out["roofline"]["note"] += ("; rank 0's own-tree and imported-tree traversals "
                                         "(both timed), interactions of rank 0")
             out["roofline"]["traffic"] = None
-            out["let_records_per_step"] = {"sent_rank0": stepper.last_sent,
-                                           "received_rank0": stepper.last_received}
+            st = let_stats
+            out["let_records_per_step"] = {"sent_rank0": st["records_sent"],
+                                           "received_rank0": st["records_received"]}
+            out["domain_rank0"] = {"particles": st["n_local"], "first_key": st["splitters"][0],
+                                   "end_key": st["splitters"][1]}
         if evolved is not None:
             out["after_collapse"] = evolved
         if alt is not None:

@@ -320,46 +320,147 @@ int nbody_direct_energy_dev_noalloc(const float *posm, const float *vx, const fl
 int nbody_set_traversal_range(nbody_t *sim, int32_t group_begin, int32_t group_end);
 int nbody_finish_step(nbody_t *sim);
 
-/* Multi-GPU domain decomposition with a locally-essential-tree exchange.  The reference is
- * single-GPU (its update() is src/cuda/simulation.cu:224-238); these four calls are what a
- * one-process-per-GPU caller adds around nbody_update() when every GPU OWNS a fixed subset
- * of the particles instead of holding all of them:
- *   1. nbody_update() with nbody_set_traversal_range(0, ngroups): kick-drift, sort, build and
- *      the traversal of the own tree, velocity kick deferred;
- *   2. nbody_get_bbox() -> all-gather of the boxes;
- *   3. nbody_let_export(): for every remote box, the (x,y,z,m) records -- centres of mass of
- *      nodes the whole box accepts under the opening criterion, and the particles of leaves
- *      it cannot -- that the remote bodies need from this tree; all-to-all of the records;
- *   4. nbody_set_sources_dev() on a second handle builds a tree over the received records,
+/* ---------------------------------------------------------------------------------------
+ * Multi-GPU domain decomposition along the Morton curve with a locally-essential-tree (LET)
+ * exchange.  The reference is single-GPU (its update() is src/cuda/simulation.cu:224-238); the
+ * scheme is the hybrid distributed octree of the paper its README cites (Cazalbou et al.,
+ * PASC'24, README.md:78): every GPU OWNS the particles of one contiguous range of Morton keys,
+ * builds a tree over them alone, tells the others about its domain through the top of that
+ * tree, and ships to every other domain only the part of its tree that domain's bodies can
+ * ever touch.  One process per GPU.  Per step and domain:
+ *   1. nbody_update() with nbody_set_traversal_range(0, 0): kick-drift, sort, build, centres of
+ *      mass of the own tree, no forces yet;
+ *   2. nbody_let_frontier_dev(): the top of the own tree -- at most 32 nodes that hold every
+ *      particle once, each with the tight box of its particles, centre of mass, mass, size;
+ *      ALL-GATHER of the frontiers;
+ *   3. nbody_let_export_dev(): for every remote domain the (x,y,z,m) records it needs from
+ *      this tree -- (centre of mass, mass) of nodes that pass the opening criterion against
+ *      the nearest of the domain's frontier boxes, the particles of leaves that do not;
+ *      ALL-TO-ALL of the record counts, then of the records;
+ *   4. nbody_traverse_from(own, own, 0) (runs while the records travel), nbody_set_sources_dev()
+ *      on a second handle builds a tree over the received records,
  *      nbody_traverse_from(own, second, 1) adds their attraction, nbody_finish_step() kicks.
+ * Every few hundred steps the key ranges are re-drawn from a global histogram of key prefixes
+ * (all-gather) and particles migrate (all-to-all).  nbody_dd_* below runs this choreography
+ * natively over caller-supplied collectives; the pieces are exported as well.
  *
  * nbody_get_bbox: lo_hi[0..2] = min, lo_hi[3..5] = max of the handle's current positions.
- * nbody_let_export: boxes = nboxes x 6 floats (host, same layout), nboxes <= 256; records of
- *   box b are written to out_dev + 4*capacity*b (device, float4 each, order unspecified);
- *   counts[b] (host) = records box b needs.  NBODY_ERR_CAPACITY if any count > capacity
- *   (counts are still valid: call again with a larger buffer).
+ * nbody_let_frontier[_dev]: max_records in [1, 32] records of 12 floats each -- lo xyz, hi xyz,
+ *   centre of mass xyz, mass, cell size, particle count -- ordered by first particle; unused
+ *   records are empty boxes (lo = 3e38, hi = 0).  _dev writes device memory on the handle's
+ *   stream and does not synchronise.
+ * nbody_let_export_dev: frontiers_dev = ndomains x records_per_domain records (device); domain
+ *   skip_domain (the caller's own; -1 = none) gets nothing; records of domain d are written to
+ *   out_dev + 4*capacity*d (device, float4 each, order unspecified); counts_dev[d] (device) =
+ *   records domain d needs, which may exceed capacity (then out_dev holds none of the surplus:
+ *   call again with a larger buffer).  Nothing is read back; ndomains <= 256.
+ * nbody_let_export: the same for nboxes <= 256 domains of ONE box each (host array of nboxes x
+ *   6 floats), counts returned to the host; NBODY_ERR_CAPACITY if any count > capacity.
  * nbody_set_sources_dev: replace the handle's particles by `count` (x,y,z,m) device records,
- *   0 <= count <= num_points, velocities zero, then sort + build + centres of mass.  The
- *   handle keeps that size until the next set_sources/set_state/spawn.
+ *   0 <= count <= num_points, velocities zero, then sort + build + centres of mass, all queued
+ *   on the handle's stream (the records must be complete on that stream; nothing is read
+ *   back).  The handle keeps that size until the next set_sources/set_state/spawn.
  * nbody_traverse_from: accelerations of `sim`'s particles due to the tree of `sources` (same
  *   device and key width; theta/softening/gravity of `sim`); added to ax/ay/az when
- *   accumulate != 0. */
+ *   accumulate != 0.  Ordered after the work queued on the sources' stream by an event, not
+ *   by a host wait. */
 /* nbody_set_particles: replace the handle's particles by `count` particles, 1 <= count <=
  *   num_points, given as host arrays: positions, velocities (NULL = 0), masses, the
  *   accelerations of their last force evaluation (NULL = 0) and caller-defined 32-bit ids
  *   (NULL = 0..count-1).  Sorts and builds like nbody_set_state but keeps accelerations and
- *   ids, so the step sequence continues as if the particles had always lived here: this is
- *   how particles migrate between the domains when the decomposition is re-balanced.  The
+ *   ids, so the step sequence continues as if the particles had always lived here.  The
  *   handle keeps that count until the next set_particles/set_state/spawn. */
 int nbody_set_particles(nbody_t *sim, int32_t count, const float *x, const float *y,
                         const float *z, const float *vx, const float *vy, const float *vz,
                         const float *m, const float *ax, const float *ay, const float *az,
                         const uint32_t *id);
 int nbody_get_bbox(nbody_t *sim, float *lo_hi);
+int nbody_let_frontier(nbody_t *sim, float *records, int32_t max_records);
+int nbody_let_frontier_dev(nbody_t *sim, float *records_dev, int32_t max_records);
 int nbody_let_export(nbody_t *sim, const float *boxes, int32_t nboxes, float *out_dev,
                      int32_t capacity, int32_t *counts);
+int nbody_let_export_dev(nbody_t *sim, const float *frontiers_dev, int32_t ndomains,
+                         int32_t records_per_domain, int32_t skip_domain, float *out_dev,
+                         int32_t capacity, int32_t *counts_dev);
 int nbody_set_sources_dev(nbody_t *sim, const float *posm_dev, int32_t count);
 int nbody_traverse_from(nbody_t *sim, nbody_t *sources, int32_t accumulate);
+
+/* Host-side sampler for a slice of a particle set: particles [first, first + count) of n_total
+ * (nbody_sample_ic = first 0, count n_total).  A particle's draws depend only on (seed, its
+ * index in the whole set), so processes that sample disjoint slices hold, together, exactly
+ * the set one process would sample. */
+int nbody_sample_ic_range(int kind, int64_t first, int32_t count, int64_t n_total, uint64_t seed,
+                          float domain_size, float gravity, float p0, float p1, float *x, float *y,
+                          float *z, float *vx, float *vy, float *vz, float *m);
+
+/* The collectives nbody_dd_* needs, supplied by the caller (RCCL in a C++ host, see
+ * INTEGRATION.md; torch.distributed in the Python binding).  Both work on DEVICE memory, are
+ * ordered like kernels on the given hipStream_t (work queued on the stream before the call
+ * precedes the collective, work queued after it follows), must not block the host longer than
+ * enqueueing takes, and return 0 on success.
+ *   all_gather: every rank contributes `bytes` at send_dev; recv_dev receives size * bytes,
+ *     rank-major.
+ *   all_to_all: send_bytes[r] bytes at send_dev + send_off[r] go to rank r, recv_bytes[r] bytes
+ *     from rank r arrive at recv_dev + recv_off[r] (host arrays of `size` entries, valid only
+ *     during the call; entries may be 0). */
+typedef struct nbody_comm {
+    int32_t rank, size;
+    void *ctx;
+    int (*all_gather)(void *ctx, const void *send_dev, void *recv_dev, size_t bytes, void *stream);
+    int (*all_to_all)(void *ctx, const void *send_dev, const size_t *send_bytes,
+                      const size_t *send_off, void *recv_dev, const size_t *recv_bytes,
+                      const size_t *recv_off, void *stream);
+} nbody_comm;
+
+typedef struct nbody_dd nbody_dd_t;
+
+/* Domain decomposition over comm->size processes, this one's particles in `own` (a float
+ * handle, created with head-room: num_points >= the most particles the domain will ever hold;
+ * the handle stays the caller's, and stays usable for getters).  *comm is copied. */
+int nbody_dd_create(nbody_t *own, const nbody_comm *comm, nbody_dd_t **out);
+void nbody_dd_destroy(nbody_dd_t *dd);
+const char *nbody_dd_last_error(nbody_dd_t *dd);
+/* Initial conditions of n_total particles (kind, p0, p1 as nbody_sample_ic, seed and physics
+ * of the handle): every rank samples n_total / size consecutive indices, ids = the global
+ * index, then nbody_dd_rebalance() distributes them.  No rank ever holds the whole set. */
+int nbody_dd_spawn(nbody_dd_t *dd, int kind, int64_t n_total, float p0, float p1);
+/* Re-draws the domains as contiguous Morton-key ranges of (nearly) equal particle counts and
+ * migrates the particles: rounds of 4096-bin histograms of key prefixes (12 more bits per
+ * round, all-gather; a cut leaves the rounds as soon as a bin edge lies within 0.5 % of a
+ * domain's share of its target, and takes the coarsest such cell boundary),
+ * one all-to-all of 44-byte particle records (accelerations and ids included, so the step
+ * sequence continues unchanged).  Call between steps; synchronises.  NBODY_ERR_CAPACITY if a
+ * domain would exceed its handle's num_points. */
+int nbody_dd_rebalance(nbody_dd_t *dd);
+/* One step of the whole system (collective: every rank calls it).  One host wait per call
+ * (for the record counts); everything else is queued. */
+int nbody_dd_step(nbody_dd_t *dd);
+/* Current decomposition: splitters[0..size] = first key of each domain (63- or 30-bit keys
+ * widened; splitters[size] = 2^bits), and counters of the last step.  Pointers may be NULL. */
+typedef struct nbody_dd_stats {
+    int64_t n_local;            /* particles this rank owns                       */
+    int64_t records_sent;       /* LET records exported in the last step          */
+    int64_t records_received;   /* LET records imported in the last step          */
+    int64_t migrated_out;       /* particles given away by the last rebalance     */
+    int32_t frontier_records;   /* frontier nodes advertised in the last step     */
+    int32_t export_capacity;    /* records per destination the export buffer holds */
+} nbody_dd_stats;
+int nbody_dd_get_stats(nbody_dd_t *dd, nbody_dd_stats *out, uint64_t *splitters);
+/* Pure host function behind nbody_dd_rebalance: cut positions from a global histogram.
+ * hist[nbins] = particles per bin (bins in key order), parts domains, slack = tolerated
+ * deviation of a cut from its target in particles.  For cut k = 1..parts-1 writes
+ * edge[k-1] = the bin edge in [0, nbins] chosen (the coarsest edge -- most trailing zero bits
+ * -- whose cumulative count lies within slack of k * total / parts) or -1 if no edge is
+ * within slack, in which case bin[k-1] = the bin that holds the target. */
+void nbody_dd_choose_edges(const uint64_t *hist, int32_t nbins, int32_t parts, uint64_t slack,
+                           int32_t *edge, int32_t *bin);
+/* Refinement round for a cut that no edge so far met: hist[nbins] = particles per sub-bin of
+ * the bin that holds the target, base_count = particles before that bin, base_edge = index of
+ * the bin's first sub-bin edge among all edges of this resolution, edge_bits = key bits that
+ * resolution has.  Returns the sub-bin edge in [0, nbins]: the coarsest within slack of
+ * target, else the nearest. */
+int32_t nbody_dd_refine_edge(const uint64_t *hist, int32_t nbins, uint64_t base_count, uint64_t target,
+                             uint64_t slack, uint64_t base_edge, int32_t edge_bits);
 
 #ifdef __cplusplus
 }

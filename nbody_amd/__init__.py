@@ -70,6 +70,26 @@ class COctreeView(C.Structure):
     _fields_ = [(k, C.c_void_p) for k, _ in _OCT_FIELDS]
 
 
+class CComm(C.Structure):
+    """struct nbody_comm: the collectives nbody_dd_* calls back into."""
+    ALL_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+    ALL_TO_ALL = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t),
+                             C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t),
+                             C.POINTER(C.c_size_t), C.c_void_p)
+    _fields_ = [("rank", C.c_int32), ("size", C.c_int32), ("ctx", C.c_void_p),
+                ("all_gather", ALL_GATHER), ("all_to_all", ALL_TO_ALL)]
+
+
+class CDDStats(C.Structure):
+    _fields_ = [("n_local", C.c_int64), ("records_sent", C.c_int64), ("records_received", C.c_int64),
+                ("migrated_out", C.c_int64), ("frontier_records", C.c_int32),
+                ("export_capacity", C.c_int32)]
+
+
+LET_REC = 12          # floats per frontier record: lo xyz, hi xyz, com xyz, mass, size, count
+LET_MAX_RECORDS = 32  # frontier records per domain
+
+
 class CTimings(C.Structure):
     _fields_ = [("steps", C.c_int32), ("ms_integrate", C.c_float), ("ms_sort", C.c_float),
                 ("ms_build", C.c_float), ("ms_com", C.c_float), ("ms_traverse", C.c_float),
@@ -88,6 +108,10 @@ EXPORTS = [
     "nbody_tree_energy", "nbody_set_state_f64", "nbody_get_state_f64", "nbody_sample_ic_f64",
     "nbody_get_octree_com_f64", "nbody_direct_sum_f64", "nbody_get_device_ptrs_f64",
     "nbody_direct_energy_dev", "nbody_direct_energy_dev_noalloc",
+    "nbody_let_frontier", "nbody_let_frontier_dev", "nbody_let_export_dev", "nbody_sample_ic_range",
+    "nbody_dd_create", "nbody_dd_destroy", "nbody_dd_last_error", "nbody_dd_spawn",
+    "nbody_dd_rebalance", "nbody_dd_step", "nbody_dd_get_stats", "nbody_dd_choose_edges",
+    "nbody_dd_refine_edge",
 ]
 
 _lib = None
@@ -162,6 +186,27 @@ def load_library() -> C.CDLL:
     lib.nbody_direct_energy_dev.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_float, C.c_float,
                                                               C.c_void_p, C.c_void_p]
     lib.nbody_direct_energy_dev_noalloc.argtypes = lib.nbody_direct_energy_dev.argtypes
+    lib.nbody_let_frontier.argtypes = [C.c_void_p, fp, C.c_int32]
+    lib.nbody_let_frontier_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    lib.nbody_let_export_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                         C.c_void_p, C.c_int32, C.c_void_p]
+    lib.nbody_sample_ic_range.argtypes = [C.c_int, C.c_int64, C.c_int32, C.c_int64, C.c_uint64,
+                                          C.c_float, C.c_float, C.c_float, C.c_float] + [fp] * 7
+    lib.nbody_dd_create.argtypes = [C.c_void_p, C.POINTER(CComm), C.POINTER(C.c_void_p)]
+    lib.nbody_dd_destroy.argtypes = [C.c_void_p]
+    lib.nbody_dd_destroy.restype = None
+    lib.nbody_dd_last_error.argtypes = [C.c_void_p]
+    lib.nbody_dd_last_error.restype = C.c_char_p
+    lib.nbody_dd_spawn.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float]
+    lib.nbody_dd_rebalance.argtypes = [C.c_void_p]
+    lib.nbody_dd_step.argtypes = [C.c_void_p]
+    lib.nbody_dd_get_stats.argtypes = [C.c_void_p, C.POINTER(CDDStats), C.POINTER(C.c_uint64)]
+    lib.nbody_dd_choose_edges.argtypes = [C.POINTER(C.c_uint64), C.c_int32, C.c_int32, C.c_uint64,
+                                          C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.nbody_dd_choose_edges.restype = None
+    lib.nbody_dd_refine_edge.argtypes = [C.POINTER(C.c_uint64), C.c_int32, C.c_uint64, C.c_uint64,
+                                         C.c_uint64, C.c_uint64, C.c_int32]
+    lib.nbody_dd_refine_edge.restype = C.c_int32
     _lib = lib
     return lib
 
@@ -186,6 +231,40 @@ def sample_ic(kind: int, n: int, seed: int = 42, domain_size: float = 5.0, gravi
     if rc != OK:
         raise RuntimeError(f"nbody_sample_ic failed with status {rc}")
     return out
+
+
+def sample_ic_range(kind: int, first: int, count: int, n_total: int, seed: int = 42,
+                    domain_size: float = 5.0, gravity: float = 1.0, p0: float = 0.0, p1: float = 0.0):
+    """Particles [first, first + count) of the n_total-particle set sample_ic(kind, n_total, seed)
+    returns (float32): a particle's draws depend on its index in the whole set only."""
+    lib = load_library()
+    out = {k: np.empty(count, np.float32) for k in ("x", "y", "z", "vx", "vy", "vz", "m")}
+    rc = lib.nbody_sample_ic_range(kind, first, count, n_total, seed, domain_size, gravity, p0, p1,
+                                   *[_fptr(out[k]) for k in ("x", "y", "z", "vx", "vy", "vz", "m")])
+    if rc != OK:
+        raise RuntimeError(f"nbody_sample_ic_range failed with status {rc}")
+    return out
+
+
+def choose_edges(hist, parts: int, slack: int):
+    """nbody_dd_choose_edges: (edge, bin) arrays of parts - 1 entries for a histogram of
+    particle counts per key-ordered bin (host code of the library, no GPU involved)."""
+    lib = load_library()
+    h = np.ascontiguousarray(hist, np.uint64)
+    edge = np.empty(max(parts - 1, 0), np.int32)
+    bin_ = np.empty(max(parts - 1, 0), np.int32)
+    lib.nbody_dd_choose_edges(h.ctypes.data_as(C.POINTER(C.c_uint64)), len(h), parts, int(slack),
+                              edge.ctypes.data_as(C.POINTER(C.c_int32)),
+                              bin_.ctypes.data_as(C.POINTER(C.c_int32)))
+    return edge, bin_
+
+
+def refine_edge(hist, base_count: int, target: int, slack: int, base_edge: int, edge_bits: int) -> int:
+    """nbody_dd_refine_edge (host code of the library)."""
+    h = np.ascontiguousarray(hist, np.uint64)
+    return int(load_library().nbody_dd_refine_edge(h.ctypes.data_as(C.POINTER(C.c_uint64)), len(h),
+                                                   int(base_count), int(target), int(slack),
+                                                   int(base_edge), int(edge_bits)))
 
 
 @dataclass
@@ -433,6 +512,23 @@ class Simulation:
         out = np.empty(6, np.float32)
         self._check(self._lib.nbody_get_bbox(self._h, _fptr(out)))
         return out
+
+    def let_frontier(self, max_records: int = LET_MAX_RECORDS) -> np.ndarray:
+        """(max_records, 12) float32: the top of the tree -- at most max_records nodes that hold
+        every particle once: lo xyz, hi xyz of the node's particles, centre of mass xyz, mass,
+        cell size, particle count; unused records are empty boxes (lo = 3e38)."""
+        out = np.empty((max_records, LET_REC), np.float32)
+        self._check(self._lib.nbody_let_frontier(self._h, _fptr(out), max_records))
+        return out
+
+    def let_frontier_dev(self, records_dev_ptr: int, max_records: int = LET_MAX_RECORDS):
+        self._check(self._lib.nbody_let_frontier_dev(self._h, records_dev_ptr, max_records))
+
+    def let_export_dev(self, frontiers_dev_ptr: int, ndomains: int, records_per_domain: int,
+                       skip_domain: int, out_dev_ptr: int, capacity: int, counts_dev_ptr: int):
+        self._check(self._lib.nbody_let_export_dev(self._h, frontiers_dev_ptr, ndomains,
+                                                   records_per_domain, skip_domain, out_dev_ptr,
+                                                   capacity, counts_dev_ptr))
 
     def let_export(self, boxes, out_dev_ptr: int, capacity: int) -> np.ndarray:
         """Writes the records every box needs to out_dev_ptr + 16*capacity*b; returns the

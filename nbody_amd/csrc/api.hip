@@ -56,7 +56,8 @@ void free_all(Sim *s)
     F(s->o_le); F(s->o_level); F(s->o_pb); F(s->o_pe); F(s->o_parent); F(s->o_size); F(s->o_wsum);
     F(s->nodeA); F(s->nodeB); F(s->list_len); F(s->inter_dev); F(s->trav_tail); F(s->trav_heavy_ctrl); F(s->pot);
     F(s->tw_posm); F(s->tw_pot); F(s->ds_pot); F(s->let_boxes); F(s->let_counts);
-    F(s->red_scratch); F(s->red_out);
+    F(s->red_scratch); F(s->red_out); F(s->let_mask); F(s->let_seg); F(s->let_frontier);
+    if (s->ev_ready) (void) hipEventDestroy(s->ev_ready);
     if (s->red_host) (void) hipHostFree(s->red_host);
     for (int k = 0; k < 3; ++k) { F(s->tw_v[k]); F(s->tw_vh[k]); F(s->tw_a[k]); F(s->ds_a[k]); }
     State64 &d = s->d;
@@ -182,8 +183,14 @@ int alloc_all(Sim *s)
         NB_HIP(s, dalloc(&s->trav_tail, 1));
         NB_HIP(s, hipMemcpy(s->trav_tail, &t, sizeof t, hipMemcpyHostToDevice));
     }
-    NB_HIP(s, dalloc(&s->let_boxes, (size_t) 6 * LET_MAX_BOXES));
+    NB_HIP(s, dalloc(&s->let_boxes, (size_t) LET_REC * LET_MAX_BOXES));
     NB_HIP(s, dalloc(&s->let_counts, (size_t) LET_MAX_BOXES + 8));
+    if (!s->fp64) {
+        NB_HIP(s, dalloc(&s->let_mask, 2 * n));
+        NB_HIP(s, dalloc(&s->let_seg, (size_t) LET_MAX_T + 2));
+        NB_HIP(s, dalloc(&s->let_frontier, (size_t) LET_MAX_T * LET_REC));
+    }
+    NB_HIP(s, hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming));
     const size_t red_bytes = reduce_scratch_bytes(REDUCE_MAX_BLOCKS, 3);
     NB_HIP(s, hipMalloc((void **) &s->red_scratch, red_bytes));
     NB_HIP(s, hipMemsetAsync(s->red_scratch, 0, red_bytes, s->stream));
@@ -239,13 +246,17 @@ inline double normal(uint64_t seed, uint64_t i, uint64_t k, double mean, double 
 }
 
 // R = float or double: the samples are drawn in double and stored in the handle's precision.
+// Particles [first, first + count) of a set of n_total: a particle's draws depend on its index
+// in the whole set only, so ranks that sample disjoint index ranges produce the same set.
 template <typename R>
-int sample_ic(int kind, int n, uint64_t seed, float domain, float gravity, float p0, float p1,
-              R *x, R *y, R *z, R *vx, R *vy, R *vz, R *m)
+int sample_ic(int kind, int count, uint64_t seed, float domain, float gravity, float p0, float p1,
+              R *x, R *y, R *z, R *vx, R *vy, R *vz, R *m, long long first = 0, long long n_total = -1)
 {
     const double c = domain * 0.5;
+    const long long n = n_total < 0 ? count : n_total;
     auto clampd = [&](double v) { return (R) std::max(0.0, std::min((double) domain, v)); };
-    for (int i = 0; i < n; ++i) {
+    for (int idx = 0; idx < count; ++idx) {
+        const long long i = first + idx;
         double px = c, py = c, pz = c, ux = 0, uy = 0, uz = 0, mass = 1.0;
         switch (kind) {
         case 0:  // uniform cube of side 1 (initial_conditions.cuh:20-47, simulation.cu:170-182)
@@ -299,11 +310,11 @@ int sample_ic(int kind, int n, uint64_t seed, float domain, float gravity, float
         }
         default: return NBODY_ERR_INVALID;
         }
-        x[i] = clampd(px); y[i] = clampd(py); z[i] = clampd(pz);
-        if (vx) vx[i] = (R) ux;
-        if (vy) vy[i] = (R) uy;
-        if (vz) vz[i] = (R) uz;
-        m[i] = (R) mass;
+        x[idx] = clampd(px); y[idx] = clampd(py); z[idx] = clampd(pz);
+        if (vx) vx[idx] = (R) ux;
+        if (vy) vy[idx] = (R) uy;
+        if (vz) vz[idx] = (R) uz;
+        m[idx] = (R) mass;
     }
     return NBODY_OK;
 }
@@ -462,7 +473,6 @@ int spawn(Sim *s, int kind, float p0, float p1)
 int validator_step(Sim *s)
 {
     const int n = s->n;
-    const size_t b = (size_t) n * 4;
     const int c = s->cur;
     const float eps2 = s->p.softening_factor * s->p.softening_factor;
     const float G = s->p.gravity;
@@ -503,7 +513,6 @@ int validator_step64(Sim *s)
 {
     State64 &d = s->d;
     const int n = s->n;
-    const size_t b = (size_t) n * 8;
     const int c = s->cur;
     const double eps = (double) s->p.softening_factor, eps2 = eps * eps;
     const double G = (double) s->p.gravity, dt = (double) s->p.dt;
@@ -563,6 +572,45 @@ int set_particles(Sim *s, int count, const R *x, const R *y, const R *z, const R
     }
     return NBODY_OK;
 }
+
+}  // namespace
+
+namespace nb {
+
+int install_particles_dev(Sim *s, int n)
+{
+    if (s->fp64) return fail(s, NBODY_ERR_STATE, "install_particles: float handles only");
+    if (n < 1 || n > s->cap) return fail(s, NBODY_ERR_CAPACITY, "install_particles: count outside [1, num_points]");
+    s->n = n;
+    NB_HIP(s, hipMemsetAsync(s->counts, 0, sizeof(Counts), s->stream));
+    NB_HIP(s, launch_morton_only(s));
+    int rc = build_after_encode(s, true);   // permutes x,y,z,m,v,vh,id: the accelerations ride in vh
+    if (rc) return rc;
+    const int c = s->cur;
+    const size_t b = (size_t) n * sizeof(float);
+    NB_HIP(s, hipMemcpyAsync(s->ax, s->vhx[c], b, hipMemcpyDeviceToDevice, s->stream));
+    NB_HIP(s, hipMemcpyAsync(s->ay, s->vhy[c], b, hipMemcpyDeviceToDevice, s->stream));
+    NB_HIP(s, hipMemcpyAsync(s->az, s->vhz[c], b, hipMemcpyDeviceToDevice, s->stream));
+    NB_HIP(s, launch_build(s));
+    NB_HIP(s, launch_com(s));
+    NB_HIP(s, launch_export_view(s));
+    s->spawned = true;
+    s->pending_vel = false;
+    s->ev_pending = 0;
+    s->t_acc = nbody_timings{};
+    return NBODY_OK;
+}
+
+int sample_ic_range(int kind, long long first, int count, long long n_total, uint64_t seed, float domain,
+                    float gravity, float p0, float p1, float *x, float *y, float *z, float *vx,
+                    float *vy, float *vz, float *m)
+{
+    return sample_ic<float>(kind, count, seed, domain, gravity, p0, p1, x, y, z, vx, vy, vz, m, first, n_total);
+}
+
+}  // namespace nb
+
+namespace {
 
 // Device array of the handle's precision Src copied out to a host array of type Dst.
 template <typename Dst, typename Src>
@@ -1150,18 +1198,68 @@ int nbody_let_export(nbody_t *h, const float *boxes, int32_t nboxes, float *out_
         return fail(s, NBODY_ERR_INVALID, "let_export: bad arguments");
     if (!s->spawned || s->n < 1) return fail(s, NBODY_ERR_STATE, "let_export before spawn/set_state");
     if (nboxes == 0) return NBODY_OK;
-    NB_HIP(s, hipMemcpyAsync(s->let_boxes, boxes, (size_t) nboxes * 24, hipMemcpyHostToDevice, s->stream));
-    NB_HIP(s, hipMemsetAsync(s->let_counts, 0, (size_t) nboxes * 4, s->stream));
-    NB_HIP(s, launch_let_export(s, s->let_boxes, nboxes, reinterpret_cast<Float4 *>(out_dev),
-                                capacity, s->let_counts));
+    // every box is a remote domain described by one frontier record
+    std::vector<float> rec((size_t) nboxes * LET_REC, 0.f);
+    for (int i = 0; i < nboxes; ++i) std::memcpy(&rec[(size_t) i * LET_REC], boxes + 6 * i, 6 * sizeof(float));
+    NB_HIP(s, hipMemcpyAsync(s->let_boxes, rec.data(), rec.size() * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    for (int b0 = 0; b0 < nboxes; b0 += LET_MASK_DOMAINS) {
+        const int nd = std::min(LET_MASK_DOMAINS, nboxes - b0);
+        NB_HIP(s, launch_let_export(s, s->let_boxes + (size_t) b0 * LET_REC, nd, 1, -1,
+                                    reinterpret_cast<Float4 *>(out_dev) + (size_t) b0 * capacity, capacity,
+                                    s->let_counts + b0));
+    }
     NB_HIP(s, hipMemcpyAsync(counts, s->let_counts, (size_t) nboxes * 4, hipMemcpyDeviceToHost, s->stream));
-    NB_HIP(s, hipStreamSynchronize(s->stream));
+    NB_HIP(s, hipStreamSynchronize(s->stream));   // also keeps `rec` alive until it has been copied
     for (int i = 0; i < nboxes; ++i)
         if (counts[i] > capacity)
             return fail(s, NBODY_ERR_CAPACITY, "let_export: a box needs more records than capacity");
     return NBODY_OK;
 }
 
+int nbody_let_frontier_dev(nbody_t *h, float *records_dev, int32_t max_records)
+{
+    NB_ENTER(h);
+    NB_FLOAT_ONLY(s, "nbody_let_frontier_dev");
+    if (!records_dev || max_records < 1 || max_records > LET_MAX_T)
+        return fail(s, NBODY_ERR_INVALID, "let_frontier: max_records outside [1, 32]");
+    if (!s->spawned || s->n < 1) return fail(s, NBODY_ERR_STATE, "let_frontier of an empty handle");
+    NB_HIP(s, launch_frontier(s, records_dev, max_records));
+    return NBODY_OK;
+}
+
+int nbody_let_frontier(nbody_t *h, float *records, int32_t max_records)
+{
+    NB_ENTER(h);
+    if (!records) return fail(s, NBODY_ERR_INVALID, "null output");
+    int rc = nbody_let_frontier_dev(h, s->let_frontier, max_records);
+    if (rc) return rc;
+    NB_HIP(s, hipMemcpyAsync(records, s->let_frontier, (size_t) max_records * LET_REC * sizeof(float),
+                             hipMemcpyDeviceToHost, s->stream));
+    NB_HIP(s, hipStreamSynchronize(s->stream));
+    return NBODY_OK;
+}
+
+int nbody_let_export_dev(nbody_t *h, const float *frontiers_dev, int32_t ndomains, int32_t records_per_domain,
+                         int32_t skip_domain, float *out_dev, int32_t capacity, int32_t *counts_dev)
+{
+    NB_ENTER(h);
+    NB_FLOAT_ONLY(s, "nbody_let_export_dev");
+    if (!frontiers_dev || !out_dev || !counts_dev || ndomains < 1 || ndomains > LET_MAX_BOXES ||
+        records_per_domain < 1 || records_per_domain > LET_MAX_T || capacity < 0)
+        return fail(s, NBODY_ERR_INVALID, "let_export_dev: bad arguments");
+    if (!s->spawned || s->n < 1) return fail(s, NBODY_ERR_STATE, "let_export before spawn/set_state");
+    for (int d0 = 0; d0 < ndomains; d0 += LET_MASK_DOMAINS) {
+        const int nd = std::min(LET_MASK_DOMAINS, ndomains - d0);
+        NB_HIP(s, launch_let_export(s, frontiers_dev + (size_t) d0 * records_per_domain * LET_REC, nd,
+                                    records_per_domain, skip_domain - d0,
+                                    reinterpret_cast<Float4 *>(out_dev) + (size_t) d0 * capacity, capacity,
+                                    reinterpret_cast<uint32_t *>(counts_dev) + d0));
+    }
+    return NBODY_OK;
+}
+
+// Source handle: particles only (no velocities, no forces of its own).  Everything is queued
+// on the handle's stream; nothing is read back.
 int nbody_set_sources_dev(nbody_t *h, const float *posm_dev, int32_t count)
 {
     NB_ENTER(h);
@@ -1181,7 +1279,7 @@ int nbody_set_sources_dev(nbody_t *h, const float *posm_dev, int32_t count)
     NB_HIP(s, launch_build(s));
     NB_HIP(s, launch_com(s));
     s->spawned = true;
-    return fetch_counts(s);
+    return NBODY_OK;
 }
 
 int nbody_traverse_from(nbody_t *h, nbody_t *sources, int32_t accumulate)
@@ -1204,7 +1302,10 @@ int nbody_traverse_from(nbody_t *h, nbody_t *sources, int32_t accumulate)
         return NBODY_OK;
     }
     if (!src->spawned) return fail(s, NBODY_ERR_STATE, "traverse_from: sources hold no tree");
-    if (src != s) NB_HIP(s, hipStreamSynchronize(src->stream));
+    if (src != s) {   // the sources' tree is built on their stream: wait for it on the GPU, not here
+        NB_HIP(s, hipEventRecord(src->ev_ready, src->stream));
+        NB_HIP(s, hipStreamWaitEvent(s->stream, src->ev_ready, 0));
+    }
     // with NBODY_FLAG_TIMING up to two calls per step (own tree, imported tree) are timed and
     // their interactions counted into the record of the last nbody_update()
     const bool timed = (s->p.flags & NBODY_FLAG_TIMING) && s->ev_pending > 0;
@@ -1220,6 +1321,10 @@ int nbody_traverse_from(nbody_t *h, nbody_t *sources, int32_t accumulate)
         NB_HIP(s, hipEventRecord(s->ev[slot][EV_TF0_END + 2 * k], s->stream));
         NB_HIP(s, launch_count_interactions(s, (unsigned long long *) (s->inter_dev + slot), true));
         s->tf_calls[slot] = k + 1;
+    }
+    if (src != s) {   // the sources may be rebuilt only after this traversal has read them
+        NB_HIP(s, hipEventRecord(s->ev_ready, s->stream));
+        NB_HIP(s, hipStreamWaitEvent(src->stream, s->ev_ready, 0));
     }
     return NBODY_OK;
 }

@@ -1,0 +1,575 @@
+// dd.hip -- multi-GPU domain decomposition along the Morton curve with a locally-essential-tree
+// exchange (nbody_dd_* of include/nbody_c.h): the per-step choreography, the re-balancing of
+// the key ranges and the distributed initial conditions, over caller-supplied collectives.
+//
+// The reference is single-GPU and has none of this; the scheme is the hybrid distributed
+// octree of the paper its README cites (Cazalbou et al., PASC'24, README.md:78).
+//
+// Streams.  S = the own handle's stream, R = the import handle's stream.  A step queues
+//   S: update (kick-drift, sort, build, centres of mass) -> frontier -> ALL-GATHER frontiers ->
+//      export -> ALL-TO-ALL counts -> copy of the counts to pinned memory -> [event C] ->
+//      own-tree traversal -> (waits for R's build) traversal of the imported tree -> kick
+//   host: waits for event C only (build + export, while the GPU already runs the own-tree
+//      traversal), sizes the record exchange from the counts
+//   R: (waits for event C) ALL-TO-ALL records -> unpack, sort, build, centres of mass
+// so the record exchange and the import build run under the own-tree traversal.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "nbody_internal.hpp"
+
+using namespace nb;
+
+namespace {
+
+constexpr int DD_BINS = 4096;        // histogram bins per refinement round (12 key bits)
+constexpr int DD_BIN_BITS = 12;
+constexpr int MIG_BYTES = 44;        // migrating particle record (k_pack_particles)
+constexpr double DD_SLACK = 0.005;   // a cut may miss its target by this share of a domain
+
+struct DD {
+    Sim *own = nullptr;
+    nbody_t *remote = nullptr;       // import handle (created on first use, regrown on demand)
+    int remote_cap = 0;
+    nbody_comm comm{};
+    int T = LET_MAX_T;
+    float *fr_send = nullptr, *fr_all = nullptr;
+    Float4 *exp_buf = nullptr;
+    int exp_cap = 0;
+    int32_t *cnt_dev = nullptr;      // [2W]: records per destination, records per origin
+    int32_t *cnt_host = nullptr;     // pinned copy
+    Float4 *recv_buf = nullptr;
+    size_t recv_cap = 0;
+    hipEvent_t ev_counts = nullptr;
+    // re-balancing scratch
+    uint64_t *q_dev = nullptr;       // query keys
+    int32_t *lb_dev = nullptr;       // their positions in the sorted keys
+    uint32_t *hist_dev = nullptr, *hist_all = nullptr;
+    size_t hist_words = 0;
+    float *mig_send = nullptr, *mig_recv = nullptr;
+    size_t mig_send_cap = 0, mig_recv_cap = 0;
+    std::vector<uint64_t> splitters;
+    nbody_dd_stats stats{};
+    std::string err;
+};
+
+int dfail(DD *d, int code, const std::string &msg)
+{
+    d->err = msg;
+    return code;
+}
+
+#define DD_HIP(d, call)                                                               \
+    do {                                                                              \
+        hipError_t e_ = (call);                                                       \
+        if (e_ != hipSuccess)                                                         \
+            return dfail(d, NBODY_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+#define DD_NB(d, call)                                                                \
+    do {                                                                              \
+        int rc_ = (call);                                                             \
+        if (rc_ != NBODY_OK)                                                          \
+            return dfail(d, rc_, std::string(#call) + ": " + nbody_last_error(reinterpret_cast<nbody_t *>((d)->own))); \
+    } while (0)
+
+#define DD_COMM(d, call)                                                              \
+    do {                                                                              \
+        if ((call) != 0) return dfail(d, NBODY_ERR_STATE, std::string("collective failed: ") + #call); \
+    } while (0)
+
+struct Guard {
+    int prev = -1;
+    explicit Guard(int dev) { (void) hipGetDevice(&prev); if (prev != dev) (void) hipSetDevice(dev); }
+    ~Guard() { if (prev >= 0) (void) hipSetDevice(prev); }
+};
+
+nbody_t *H(Sim *s) { return reinterpret_cast<nbody_t *>(s); }
+
+int key_bits(const Sim *s) { return s->key_bytes == 4 ? 30 : 63; }
+
+int ensure_export_capacity(DD *d, int cap)
+{
+    if (cap <= d->exp_cap) return NBODY_OK;
+    if (d->exp_buf) DD_HIP(d, hipFree(d->exp_buf));
+    d->exp_buf = nullptr;
+    d->exp_cap = 0;
+    DD_HIP(d, hipMalloc((void **) &d->exp_buf, (size_t) d->comm.size * cap * sizeof(Float4)));
+    d->exp_cap = cap;
+    return NBODY_OK;
+}
+
+// Import handle for `count` records: the own handle's parameters, smaller leaves (a far region
+// arrives as a handful of records that would otherwise share one leaf and never be
+// approximated), no validator, no timing.
+int ensure_remote(DD *d, size_t count)
+{
+    if (count <= (size_t) d->remote_cap) return NBODY_OK;
+    if (d->remote) nbody_destroy(d->remote);
+    d->remote = nullptr;
+    d->remote_cap = 0;
+    nbody_params p = d->own->p;
+    const size_t want = std::max<size_t>(count + count / 4 + 1024, (size_t) d->own->cap / 2);
+    p.num_points = (int32_t) std::min<size_t>(want, (size_t) (1 << 29) - 1);
+    p.max_num_codes_per_leaf = std::min(8, p.max_num_codes_per_leaf);
+    p.num_steps_validator = 0;
+    p.flags = 0;
+    p.device_id = d->own->device;
+    if (nbody_create(&p, &d->remote) != NBODY_OK) return dfail(d, NBODY_ERR_HIP, "cannot create the import handle");
+    d->remote_cap = p.num_points;
+    return NBODY_OK;
+}
+
+int export_and_count(DD *d)
+{
+    Sim *s = d->own;
+    const int W = d->comm.size, me = d->comm.rank;
+    DD_NB(d, nbody_let_export_dev(H(s), d->fr_all, W, d->T, me, reinterpret_cast<float *>(d->exp_buf),
+                                  d->exp_cap, d->cnt_dev));
+    std::vector<size_t> four(W, sizeof(int32_t)), off(W);
+    for (int r = 0; r < W; ++r) off[r] = (size_t) r * sizeof(int32_t);
+    DD_COMM(d, d->comm.all_to_all(d->comm.ctx, d->cnt_dev, four.data(), off.data(), d->cnt_dev + W,
+                                  four.data(), off.data(), (void *) s->stream));
+    DD_HIP(d, hipMemcpyAsync(d->cnt_host, d->cnt_dev, (size_t) 2 * W * sizeof(int32_t),
+                             hipMemcpyDeviceToHost, s->stream));
+    DD_HIP(d, hipEventRecord(d->ev_counts, s->stream));
+    return NBODY_OK;
+}
+
+// Gathers `words` uint32 per rank and returns their element-wise sum over the ranks.
+int gather_sum(DD *d, size_t words, std::vector<uint64_t> &sum)
+{
+    Sim *s = d->own;
+    const int W = d->comm.size;
+    DD_COMM(d, d->comm.all_gather(d->comm.ctx, d->hist_dev, d->hist_all, words * sizeof(uint32_t),
+                                  (void *) s->stream));
+    std::vector<uint32_t> all(words * W);
+    DD_HIP(d, hipMemcpyAsync(all.data(), d->hist_all, all.size() * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                             s->stream));
+    DD_HIP(d, hipStreamSynchronize(s->stream));
+    sum.assign(words, 0);
+    for (int r = 0; r < W; ++r)
+        for (size_t j = 0; j < words; ++j) sum[j] += all[(size_t) r * words + j];
+    return NBODY_OK;
+}
+
+// Positions of `nq` query keys in the own sorted keys, on the host.
+int lower_bounds(DD *d, const std::vector<uint64_t> &q, std::vector<int32_t> &lb)
+{
+    Sim *s = d->own;
+    lb.assign(q.size(), 0);
+    if (s->n < 1 || !s->spawned) return NBODY_OK;   // no particles: every position is 0
+    DD_HIP(d, hipMemcpyAsync(d->q_dev, q.data(), q.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s->stream));
+    DD_HIP(d, launch_key_lower_bound(s, d->q_dev, (int) q.size(), d->lb_dev));
+    DD_HIP(d, hipMemcpyAsync(lb.data(), d->lb_dev, q.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+    DD_HIP(d, hipStreamSynchronize(s->stream));
+    return NBODY_OK;
+}
+
+int ctz_edge(uint64_t j, int width)   // trailing zeros of an edge index; the ends count as coarsest
+{
+    if (j == 0 || j == (1ull << width)) return 64;
+    return __builtin_ctzll(j);
+}
+
+}  // namespace
+
+extern "C" {
+
+void nbody_dd_choose_edges(const uint64_t *hist, int32_t nbins, int32_t parts, uint64_t slack,
+                           int32_t *edge, int32_t *bin)
+{
+    std::vector<uint64_t> P((size_t) nbins + 1, 0);
+    for (int j = 0; j < nbins; ++j) P[j + 1] = P[j] + hist[j];
+    const uint64_t total = P[nbins];
+    int width = 0;
+    while ((1 << width) < nbins) ++width;
+    for (int k = 1; k < parts; ++k) {
+        const uint64_t target = (uint64_t) ((unsigned __int128) total * (unsigned) k / (unsigned) parts);
+        int best = -1, best_tz = -1;
+        uint64_t best_dist = 0;
+        for (int j = 0; j <= nbins; ++j) {
+            const uint64_t dist = P[j] > target ? P[j] - target : target - P[j];
+            if (dist > slack) continue;
+            const int tz = ctz_edge((uint64_t) j, width);
+            if (tz > best_tz || (tz == best_tz && dist < best_dist)) { best = j; best_tz = tz; best_dist = dist; }
+        }
+        edge[k - 1] = best;
+        // the bin that holds the target: P[b] <= target < P[b + 1]
+        int b = (int) (std::upper_bound(P.begin(), P.end(), target) - P.begin()) - 1;
+        bin[k - 1] = std::max(0, std::min(nbins - 1, b));
+    }
+}
+
+int32_t nbody_dd_refine_edge(const uint64_t *hist, int32_t nbins, uint64_t base_count, uint64_t target,
+                             uint64_t slack, uint64_t base_edge, int32_t edge_bits)
+{
+    uint64_t cum = base_count, best_dist = ~0ull;
+    int best_j = 0, best_tz = -1;
+    bool in_slack = false;
+    for (int j = 0; j <= nbins; ++j) {
+        const uint64_t dist = cum > target ? cum - target : target - cum;
+        const bool ok = dist <= slack;
+        const int tz = ctz_edge(base_edge + (uint64_t) j, edge_bits);
+        // inside the slack the coarsest edge wins; with no edge inside it, the nearest
+        if (ok ? (!in_slack || tz > best_tz || (tz == best_tz && dist < best_dist))
+               : (!in_slack && dist < best_dist)) {
+            best_j = j; best_dist = dist; best_tz = tz; in_slack = in_slack || ok;
+        }
+        if (j < nbins) cum += hist[j];
+    }
+    return best_j;
+}
+
+int nbody_sample_ic_range(int kind, int64_t first, int32_t count, int64_t n_total, uint64_t seed,
+                          float domain_size, float gravity, float p0, float p1, float *x, float *y,
+                          float *z, float *vx, float *vy, float *vz, float *m)
+{
+    if (count < 0 || first < 0 || n_total < 1 || first + count > n_total || !x || !y || !z || !m)
+        return NBODY_ERR_INVALID;
+    return sample_ic_range(kind, first, count, n_total, seed, domain_size, gravity, p0, p1, x, y, z, vx,
+                           vy, vz, m);
+}
+
+int nbody_dd_create(nbody_t *own, const nbody_comm *comm, nbody_dd_t **out)
+{
+    if (!own || !comm || !out || comm->size < 1 || comm->size > LET_MAX_BOXES || comm->rank < 0 ||
+        comm->rank >= comm->size || (comm->size > 1 && (!comm->all_gather || !comm->all_to_all)))
+        return NBODY_ERR_INVALID;
+    *out = nullptr;
+    Sim *s = reinterpret_cast<Sim *>(own);
+    if (s->fp64) return NBODY_ERR_STATE;
+    DD *d = new (std::nothrow) DD();
+    if (!d) return NBODY_ERR_INVALID;
+    d->own = s;
+    d->comm = *comm;
+    const int W = comm->size;
+    Guard g(s->device);
+    auto A = [&](void **p, size_t bytes) { return hipMalloc(p, std::max<size_t>(bytes, 16)); };
+    hipError_t e = A((void **) &d->fr_send, (size_t) d->T * LET_REC * sizeof(float));
+    if (e == hipSuccess) e = A((void **) &d->fr_all, (size_t) W * d->T * LET_REC * sizeof(float));
+    if (e == hipSuccess) e = A((void **) &d->cnt_dev, (size_t) 2 * W * sizeof(int32_t));
+    if (e == hipSuccess) e = hipHostMalloc((void **) &d->cnt_host, (size_t) 2 * W * sizeof(int32_t));
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_counts, hipEventDisableTiming);
+    // one round of histograms per cut at most: (W - 1) x 4097 queries
+    const size_t nq = (size_t) std::max(1, W - 1) * (DD_BINS + 1) + W + 1;
+    d->hist_words = (size_t) std::max(1, W - 1) * DD_BINS + W;
+    if (e == hipSuccess) e = A((void **) &d->q_dev, nq * sizeof(uint64_t));
+    if (e == hipSuccess) e = A((void **) &d->lb_dev, nq * sizeof(int32_t));
+    if (e == hipSuccess) e = A((void **) &d->hist_dev, d->hist_words * sizeof(uint32_t));
+    if (e == hipSuccess) e = A((void **) &d->hist_all, d->hist_words * W * sizeof(uint32_t));
+    if (e != hipSuccess) { nbody_dd_destroy(reinterpret_cast<nbody_dd_t *>(d)); return NBODY_ERR_HIP; }
+    if (W > 1 && ensure_export_capacity(d, std::max(4096, s->cap / 4)) != NBODY_OK) {
+        nbody_dd_destroy(reinterpret_cast<nbody_dd_t *>(d));
+        return NBODY_ERR_HIP;
+    }
+    d->splitters.assign((size_t) W + 1, 0);
+    d->splitters[W] = 1ull << key_bits(s);
+    // update() = build only: forces and kick are driven from here
+    if (nbody_set_traversal_range(own, 0, 0) != NBODY_OK) {
+        nbody_dd_destroy(reinterpret_cast<nbody_dd_t *>(d));
+        return NBODY_ERR_STATE;
+    }
+    *out = reinterpret_cast<nbody_dd_t *>(d);
+    return NBODY_OK;
+}
+
+void nbody_dd_destroy(nbody_dd_t *h)
+{
+    if (!h) return;
+    DD *d = reinterpret_cast<DD *>(h);
+    Guard g(d->own->device);
+    (void) hipStreamSynchronize(d->own->stream);
+    if (d->remote) nbody_destroy(d->remote);
+    auto F = [](void *p) { if (p) (void) hipFree(p); };
+    F(d->fr_send); F(d->fr_all); F(d->exp_buf); F(d->cnt_dev); F(d->recv_buf); F(d->q_dev); F(d->lb_dev);
+    F(d->hist_dev); F(d->hist_all); F(d->mig_send); F(d->mig_recv);
+    if (d->cnt_host) (void) hipHostFree(d->cnt_host);
+    if (d->ev_counts) (void) hipEventDestroy(d->ev_counts);
+    delete d;
+}
+
+const char *nbody_dd_last_error(nbody_dd_t *h)
+{
+    return h ? reinterpret_cast<DD *>(h)->err.c_str() : "null handle";
+}
+
+int nbody_dd_step(nbody_dd_t *h)
+{
+    if (!h) return NBODY_ERR_INVALID;
+    DD *d = reinterpret_cast<DD *>(h);
+    Sim *s = d->own;
+    Guard g(s->device);
+    const int W = d->comm.size, me = d->comm.rank;
+    // A domain may be empty (more ranks than occupied key ranges): it still takes part in
+    // every collective, with an empty frontier and no records.
+    const bool have = s->spawned && s->n > 0;
+    if (have) DD_NB(d, nbody_update(H(s)));
+    if (W == 1) {
+        if (have) {
+            DD_NB(d, nbody_traverse_from(H(s), H(s), 0));
+            DD_NB(d, nbody_finish_step(H(s)));
+        }
+        d->stats.records_sent = d->stats.records_received = 0;
+        return NBODY_OK;
+    }
+    if (have) {
+        DD_NB(d, nbody_let_frontier_dev(H(s), d->fr_send, d->T));
+    } else {   // empty boxes
+        std::vector<float> empty((size_t) d->T * LET_REC, 0.f);
+        for (int t = 0; t < d->T; ++t) empty[(size_t) t * LET_REC] = empty[(size_t) t * LET_REC + 1] = empty[(size_t) t * LET_REC + 2] = 3.0e38f;
+        DD_HIP(d, hipMemcpyAsync(d->fr_send, empty.data(), empty.size() * sizeof(float), hipMemcpyHostToDevice, s->stream));
+        DD_HIP(d, hipStreamSynchronize(s->stream));
+    }
+    DD_COMM(d, d->comm.all_gather(d->comm.ctx, d->fr_send, d->fr_all, (size_t) d->T * LET_REC * sizeof(float),
+                                  (void *) s->stream));
+    if (have) {
+        int rc = export_and_count(d);
+        if (rc) return rc;
+        // the own-tree traversal runs while the host sizes the exchange and the records travel
+        DD_NB(d, nbody_traverse_from(H(s), H(s), 0));
+    } else {
+        DD_HIP(d, hipMemsetAsync(d->cnt_dev, 0, (size_t) W * sizeof(int32_t), s->stream));
+        std::vector<size_t> four(W, sizeof(int32_t)), off(W);
+        for (int r = 0; r < W; ++r) off[r] = (size_t) r * sizeof(int32_t);
+        DD_COMM(d, d->comm.all_to_all(d->comm.ctx, d->cnt_dev, four.data(), off.data(), d->cnt_dev + W,
+                                      four.data(), off.data(), (void *) s->stream));
+        DD_HIP(d, hipMemcpyAsync(d->cnt_host, d->cnt_dev, (size_t) 2 * W * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
+        DD_HIP(d, hipEventRecord(d->ev_counts, s->stream));
+    }
+    DD_HIP(d, hipEventSynchronize(d->ev_counts));   // the step's one host wait
+    int need = 0;
+    for (int r = 0; r < W; ++r) need = std::max(need, d->cnt_host[r]);
+    if (need > d->exp_cap) {
+        // A destination needs more records than the buffer holds per destination (first steps, or
+        // the domains have changed).  The counts are the true ones either way and the peers
+        // have them already, so this is a local matter: grow the buffer and export again.
+        DD_HIP(d, hipStreamSynchronize(s->stream));
+        int rc = ensure_export_capacity(d, need + need / 4 + 1024);
+        if (rc) return rc;
+        DD_NB(d, nbody_let_export_dev(H(s), d->fr_all, W, d->T, me, reinterpret_cast<float *>(d->exp_buf),
+                                      d->exp_cap, d->cnt_dev));
+        DD_HIP(d, hipEventRecord(d->ev_counts, s->stream));
+    }
+    size_t total_recv = 0, total_send = 0;
+    std::vector<size_t> sb(W), so(W), rb(W), ro(W);
+    for (int r = 0; r < W; ++r) {
+        const size_t sc = r == me ? 0 : (size_t) d->cnt_host[r], rc = r == me ? 0 : (size_t) d->cnt_host[W + r];
+        sb[r] = sc * sizeof(Float4);
+        so[r] = (size_t) r * d->exp_cap * sizeof(Float4);
+        rb[r] = rc * sizeof(Float4);
+        ro[r] = total_recv * sizeof(Float4);
+        total_recv += rc;
+        total_send += sc;
+    }
+    d->stats.records_sent = (int64_t) total_send;
+    d->stats.records_received = (int64_t) total_recv;
+    d->stats.frontier_records = d->T;
+    d->stats.export_capacity = d->exp_cap;
+    int rc = ensure_remote(d, total_recv);
+    if (rc) return rc;
+    if (total_recv > d->recv_cap) {
+        if (d->recv_buf) DD_HIP(d, hipFree(d->recv_buf));   // implicit device synchronisation
+        d->recv_buf = nullptr;
+        d->recv_cap = 0;
+        const size_t cap = total_recv + total_recv / 4 + 1024;
+        DD_HIP(d, hipMalloc((void **) &d->recv_buf, cap * sizeof(Float4)));
+        d->recv_cap = cap;
+    }
+    Sim *rs = reinterpret_cast<Sim *>(d->remote);
+    hipStream_t R = rs ? rs->stream : s->stream;
+    DD_HIP(d, hipStreamWaitEvent(R, d->ev_counts, 0));   // the records are exported
+    DD_COMM(d, d->comm.all_to_all(d->comm.ctx, d->exp_buf, sb.data(), so.data(), d->recv_buf, rb.data(),
+                                  ro.data(), (void *) R));
+    if (rs) {
+        if (nbody_set_sources_dev(d->remote, reinterpret_cast<const float *>(d->recv_buf), (int32_t) total_recv) != NBODY_OK)
+            return dfail(d, NBODY_ERR_STATE, std::string("import build: ") + nbody_last_error(d->remote));
+    }
+    if (have) {
+        if (rs) DD_NB(d, nbody_traverse_from(H(s), d->remote, 1));
+        DD_NB(d, nbody_finish_step(H(s)));
+    }
+    return NBODY_OK;
+}
+
+int nbody_dd_rebalance(nbody_dd_t *h)
+{
+    if (!h) return NBODY_ERR_INVALID;
+    DD *d = reinterpret_cast<DD *>(h);
+    Sim *s = d->own;
+    Guard g(s->device);
+    const int W = d->comm.size, me = d->comm.rank;
+    if (s->pending_vel) return dfail(d, NBODY_ERR_STATE, "rebalance between update and finish_step");
+    const int KB = key_bits(s);
+    d->stats.migrated_out = 0;
+    d->stats.n_local = s->spawned ? s->n : 0;
+    if (W == 1) return NBODY_OK;
+    const int n_local = s->spawned ? s->n : 0;
+    // ---- round 1: 4096 bins of the top 12 key bits ----
+    std::vector<uint64_t> q(DD_BINS + 1);
+    for (int j = 0; j <= DD_BINS; ++j) q[j] = (uint64_t) j << (KB - DD_BIN_BITS);
+    std::vector<int32_t> lb;
+    int rc = lower_bounds(d, q, lb);
+    if (rc) return rc;
+    std::vector<uint32_t> local(d->hist_words, 0);
+    for (int j = 0; j < DD_BINS; ++j) local[j] = (uint32_t) (lb[j + 1] - lb[j]);
+    DD_HIP(d, hipMemcpyAsync(d->hist_dev, local.data(), DD_BINS * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+    std::vector<uint64_t> hist;
+    rc = gather_sum(d, DD_BINS, hist);
+    if (rc) return rc;
+    uint64_t total = 0;
+    std::vector<uint64_t> P1(DD_BINS + 1, 0);
+    for (int j = 0; j < DD_BINS; ++j) { P1[j + 1] = P1[j] + hist[j]; total += hist[j]; }
+    if (total == 0) return dfail(d, NBODY_ERR_STATE, "rebalance: no particles anywhere");
+    const uint64_t slack = (uint64_t) (DD_SLACK * (double) total / W);
+    std::vector<int32_t> edge(W - 1), bin(W - 1);
+    nbody_dd_choose_edges(hist.data(), DD_BINS, W, slack, edge.data(), bin.data());
+    std::vector<uint64_t> split((size_t) W + 1, 0);
+    split[W] = 1ull << KB;
+    struct Cut { int k; uint64_t prefix, base; };   // the bin (of `bits` key bits) that holds cut k's target
+    std::vector<Cut> pending;
+    for (int k = 1; k < W; ++k) {
+        if (edge[k - 1] >= 0) split[k] = (uint64_t) edge[k - 1] << (KB - DD_BIN_BITS);
+        else pending.push_back(Cut{k, (uint64_t) bin[k - 1], P1[bin[k - 1]]});
+    }
+    // ---- further rounds: the next (up to) 12 key bits of the bin each open cut falls in ----
+    for (int bits = DD_BIN_BITS; !pending.empty(); ) {
+        const int nb = std::min(DD_BIN_BITS, KB - bits);
+        const int nbins = 1 << nb, sh = KB - bits - nb;
+        const int np = (int) pending.size();
+        q.assign((size_t) np * (nbins + 1), 0);
+        for (int i = 0; i < np; ++i)
+            for (int j = 0; j <= nbins; ++j)
+                q[(size_t) i * (nbins + 1) + j] = ((pending[i].prefix << nb) + (uint64_t) j) << sh;
+        rc = lower_bounds(d, q, lb);
+        if (rc) return rc;
+        for (int i = 0; i < np; ++i)
+            for (int j = 0; j < nbins; ++j)
+                local[(size_t) i * nbins + j] = (uint32_t) (lb[(size_t) i * (nbins + 1) + j + 1] - lb[(size_t) i * (nbins + 1) + j]);
+        DD_HIP(d, hipMemcpyAsync(d->hist_dev, local.data(), (size_t) np * nbins * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+        rc = gather_sum(d, (size_t) np * nbins, hist);
+        if (rc) return rc;
+        std::vector<Cut> next;
+        for (int i = 0; i < np; ++i) {
+            const Cut c = pending[i];
+            const uint64_t *hi = &hist[(size_t) i * nbins];
+            const uint64_t target = (uint64_t) ((unsigned __int128) total * (unsigned) c.k / (unsigned) W);
+            const int j = nbody_dd_refine_edge(hi, nbins, c.base, target, slack, c.prefix << nb, bits + nb);
+            uint64_t cum = c.base;
+            for (int t = 0; t < j; ++t) cum += hi[t];
+            const uint64_t dist = cum > target ? cum - target : target - cum;
+            if (dist <= slack || bits + nb == KB) {
+                split[c.k] = ((c.prefix << nb) + (uint64_t) j) << sh;
+            } else {   // descend into the sub-bin that holds the target
+                uint64_t before = c.base;
+                int b = 0;
+                while (b + 1 < nbins && before + hi[b] <= target) { before += hi[b]; ++b; }
+                next.push_back(Cut{c.k, (c.prefix << nb) + (uint64_t) b, before});
+            }
+        }
+        pending.swap(next);
+        bits += nb;
+    }
+    for (int k = 1; k <= W; ++k) split[k] = std::max(split[k], split[k - 1]);
+    d->splitters = split;
+    // ---- migration: the destinations of the sorted particles are contiguous stretches ----
+    std::vector<uint64_t> cuts(split.begin(), split.end());
+    rc = lower_bounds(d, cuts, lb);
+    if (rc) return rc;
+    lb[0] = 0;
+    lb[W] = n_local;
+    std::vector<uint32_t> sc(W);
+    for (int r = 0; r < W; ++r) sc[r] = (uint32_t) (lb[r + 1] - lb[r]);
+    DD_HIP(d, hipMemcpyAsync(d->hist_dev, sc.data(), W * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+    DD_COMM(d, d->comm.all_gather(d->comm.ctx, d->hist_dev, d->hist_all, W * sizeof(uint32_t), (void *) s->stream));
+    std::vector<uint32_t> mat((size_t) W * W);
+    DD_HIP(d, hipMemcpyAsync(mat.data(), d->hist_all, mat.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    DD_HIP(d, hipStreamSynchronize(s->stream));
+    size_t total_recv = 0;
+    std::vector<size_t> sb(W), so(W), rb(W), ro(W);
+    for (int r = 0; r < W; ++r) {
+        sb[r] = (size_t) sc[r] * MIG_BYTES;
+        so[r] = (size_t) lb[r] * MIG_BYTES;
+        const size_t cnt = mat[(size_t) r * W + me];
+        rb[r] = cnt * MIG_BYTES;
+        ro[r] = total_recv * MIG_BYTES;
+        total_recv += cnt;
+    }
+    // (a domain that would overflow its handle still takes part in the exchange, into a buffer
+    // of the full size, and raises its error afterwards without installing anything)
+    if (!d->mig_send || (size_t) n_local > d->mig_send_cap) {
+        if (d->mig_send) DD_HIP(d, hipFree(d->mig_send));
+        d->mig_send = nullptr;
+        d->mig_send_cap = 0;
+        DD_HIP(d, hipMalloc((void **) &d->mig_send, std::max<size_t>((size_t) s->cap, n_local) * MIG_BYTES));
+        d->mig_send_cap = std::max<size_t>((size_t) s->cap, n_local);
+    }
+    if (!d->mig_recv || total_recv > d->mig_recv_cap) {
+        if (d->mig_recv) DD_HIP(d, hipFree(d->mig_recv));
+        d->mig_recv = nullptr;
+        d->mig_recv_cap = 0;
+        const size_t cap = std::max<size_t>((size_t) s->cap, total_recv);
+        DD_HIP(d, hipMalloc((void **) &d->mig_recv, cap * MIG_BYTES));
+        d->mig_recv_cap = cap;
+    }
+    if (n_local > 0) DD_HIP(d, launch_pack_particles(s, d->mig_send));
+    DD_COMM(d, d->comm.all_to_all(d->comm.ctx, d->mig_send, sb.data(), so.data(), d->mig_recv, rb.data(),
+                                  ro.data(), (void *) s->stream));
+    d->stats.migrated_out = (int64_t) n_local - (int64_t) sc[me];
+    if (total_recv > (size_t) s->cap) {
+        DD_HIP(d, hipStreamSynchronize(s->stream));
+        return dfail(d, NBODY_ERR_CAPACITY, "rebalance: the domain would hold more particles than num_points");
+    }
+    if (total_recv == 0) {
+        DD_HIP(d, hipStreamSynchronize(s->stream));
+        s->n = 0;
+        s->spawned = false;
+        d->stats.n_local = 0;
+        return NBODY_OK;
+    }
+    DD_HIP(d, launch_unpack_particles(s, d->mig_recv, (int) total_recv));
+    if (install_particles_dev(s, (int) total_recv) != NBODY_OK)
+        return dfail(d, NBODY_ERR_STATE, std::string("rebalance: ") + nbody_last_error(H(s)));
+    DD_NB(d, nbody_sync(H(s)));
+    d->stats.n_local = (int64_t) total_recv;
+    return NBODY_OK;
+}
+
+int nbody_dd_spawn(nbody_dd_t *h, int kind, int64_t n_total, float p0, float p1)
+{
+    if (!h) return NBODY_ERR_INVALID;
+    DD *d = reinterpret_cast<DD *>(h);
+    Sim *s = d->own;
+    Guard g(s->device);
+    const int W = d->comm.size, me = d->comm.rank;
+    if (n_total < W) return dfail(d, NBODY_ERR_INVALID, "spawn: fewer particles than ranks");
+    const int64_t first = n_total * me / W, last = n_total * (me + 1) / W;
+    const int count = (int) (last - first);
+    if (count > s->cap) return dfail(d, NBODY_ERR_CAPACITY, "spawn: num_points is smaller than n_total / ranks");
+    std::vector<float> x(count), y(count), z(count), vx(count), vy(count), vz(count), m(count);
+    std::vector<uint32_t> id(count);
+    int rc = sample_ic_range(kind, first, count, n_total, s->p.seed, s->p.domain_size, s->p.gravity, p0, p1,
+                             x.data(), y.data(), z.data(), vx.data(), vy.data(), vz.data(), m.data());
+    if (rc) return dfail(d, rc, "spawn: unknown initial condition kind");
+    for (int i = 0; i < count; ++i) id[i] = (uint32_t) (first + i);
+    DD_NB(d, nbody_set_particles(H(s), count, x.data(), y.data(), z.data(), vx.data(), vy.data(), vz.data(),
+                                 m.data(), nullptr, nullptr, nullptr, id.data()));
+    DD_NB(d, nbody_set_traversal_range(H(s), 0, 0));
+    return nbody_dd_rebalance(h);
+}
+
+int nbody_dd_get_stats(nbody_dd_t *h, nbody_dd_stats *out, uint64_t *splitters)
+{
+    if (!h) return NBODY_ERR_INVALID;
+    DD *d = reinterpret_cast<DD *>(h);
+    d->stats.n_local = d->own->spawned ? d->own->n : 0;
+    if (out) *out = d->stats;
+    if (splitters) std::memcpy(splitters, d->splitters.data(), d->splitters.size() * sizeof(uint64_t));
+    return NBODY_OK;
+}
+
+}  // extern "C"

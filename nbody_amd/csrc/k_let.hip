@@ -51,54 +51,236 @@ __device__ __forceinline__ float box_dist_sq(const float *__restrict__ bx, float
     return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
 }
 
-// One thread per (octree node, remote box).  A node is REACHED from the root iff none of its
-// ancestors passes the opening criterion with respect to the box, where the criterion is the
-// traversal's own  size^2 / d^2 < theta^2  with d = distance from the BOX to the node's centre
-// of mass -- never larger than the distance from any body inside the box, so whatever is
-// accepted here would be accepted by every group of the remote domain as well.  A reached
-// node exports its (com, mass) if it passes, all its particles if it is a leaf, and nothing
-// otherwise (its children decide).  No stack, no queue, no inter-thread dependency; output
-// slots come from one atomic per workgroup and box.
-__global__ __launch_bounds__(256) void k_let_export(
+// ---------------------------------------------------------------------------
+// Top of the tree ("frontier") of a handle: at most T nodes that together hold every
+// particle exactly once -- what a domain tells the other domains about itself.  The nodes
+// of the breadth-first prefix [0, K) are expanded, K the largest prefix whose expansion
+// leaves at most T nodes: the frontier is every child of an expanded node that is not itself
+// expanded, plus the leaves among the expanded ones.  Records are ordered by first particle
+// so that they tile [0, n).  A record is LET_REC floats:
+//   lo xyz, hi xyz (tight box of the node's particles, filled by k_frontier_bbox),
+//   centre of mass xyz, mass, cell size, particle count (as float).
+// Unused records are empty boxes (lo = 3e38, hi = 0), which are farther than anything.
+// One workgroup of 256 threads; T <= LET_MAX_T = 32.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_frontier_select(
+    const Counts *counts, int n, int T, const NodeB *__restrict__ nodeB,
+    const Float4 *__restrict__ nodeA, const int32_t *__restrict__ o_pb,
+    const int32_t *__restrict__ o_pe, float *__restrict__ rec, int32_t *__restrict__ seg)
+{
+    __shared__ uint32_t s_scan[5];
+    __shared__ int s_size[LET_MAX_T + 1];   // frontier size after expanding the prefix [0, K)
+    __shared__ int s_K, s_C, s_F;
+    __shared__ int s_node[LET_MAX_T], s_first[LET_MAX_T];
+    const int tid = threadIdx.x;
+    const int n_oct = counts->n_oct;
+    const int L = min(n_oct, T);
+    // growth of the frontier when node t is expanded: children - 1 (a leaf stays as it is)
+    uint32_t inc = 0;
+    if (tid < L) {
+        const NodeB b = nodeB[tid];
+        inc = (b.meta & NODE_LEAF) ? 0u : (uint32_t) (b.count - 1);
+    }
+    uint32_t tot;
+    const uint32_t excl = block_excl_scan_u32<4>(inc, s_scan, &tot);
+    if (tid <= L) s_size[tid] = 1 + (int) excl;   // size after expanding [0, tid)
+    if (tid == 0) { s_K = 0; s_C = 1; s_F = 0; }
+    __syncthreads();
+    if (tid <= L && s_size[tid] <= T) atomicMax(&s_K, tid);   // sizes do not decrease with K
+    __syncthreads();
+    const int K = s_K;
+    // nodes [0, C) are the root and all children of expanded nodes (breadth-first numbering)
+    if (tid < K) {
+        const NodeB b = nodeB[tid];
+        if (!(b.meta & NODE_LEAF)) atomicMax(&s_C, b.first + b.count);
+    }
+    __syncthreads();
+    const int C = s_C;
+    for (int base = 0; base < C; base += 256) {   // C <= 1 + 8 T: two rounds at most
+        const int o = base + tid;
+        bool in = false;
+        if (o < C) in = o >= K || (nodeB[o].meta & NODE_LEAF);
+        uint32_t t2;
+        const uint32_t ex = block_excl_scan_u32<4>(in ? 1u : 0u, s_scan, &t2);
+        const int at = s_F + (int) ex;
+        if (in && at < LET_MAX_T) { s_node[at] = o; s_first[at] = o_pb[o]; }
+        __syncthreads();
+        if (tid == 0) s_F += (int) t2;
+        __syncthreads();
+    }
+    const int F = min(s_F, T);   // == s_F by construction
+    if (tid < T) {
+        float *r = rec + (size_t) tid * LET_REC;
+        if (tid < F) {
+            // slot = rank of this node's first particle among the frontier nodes
+            int slot = 0;
+            for (int j = 0; j < F; ++j) slot += s_first[j] < s_first[tid];
+            r = rec + (size_t) slot * LET_REC;
+            const int o = s_node[tid];
+            const Float4 A = nodeA[o];
+            r[0] = r[1] = r[2] = 3.0e38f;
+            r[3] = r[4] = r[5] = 0.f;
+            r[6] = A.x; r[7] = A.y; r[8] = A.z; r[9] = A.w;
+            r[10] = nodeB[o].size;
+            r[11] = (float) (o_pe[o] - o_pb[o] + 1);
+            seg[slot] = s_first[tid];
+        } else {
+            r[0] = r[1] = r[2] = 3.0e38f;
+            for (int k = 3; k < LET_REC; ++k) r[k] = 0.f;
+        }
+    }
+    if (tid == 0) { seg[F] = n; seg[LET_MAX_T + 1] = F; }
+}
+
+// Tight boxes of the frontier nodes: one pass over the particles, each finds its node by
+// binary search over the <= T first-particle indices; a wave whose 64 particles share a node
+// (nearly all do) reduces first and issues one atomic per bound.  Positions are >= 0, so the
+// order of the floats is the order of their bit patterns.
+__global__ __launch_bounds__(256) void k_frontier_bbox(int n, const Float4 *__restrict__ posm,
+                                                       const int32_t *__restrict__ seg,
+                                                       float *__restrict__ rec)
+{
+    __shared__ int s_seg[LET_MAX_T + 1];
+    __shared__ uint32_t s_box[LET_MAX_T][6];
+    const int tid = threadIdx.x;
+    const int F = seg[LET_MAX_T + 1];
+    if (tid <= F) s_seg[tid] = seg[tid];
+    if (tid < LET_MAX_T * 6) (&s_box[0][0])[tid] = (tid % 6) < 3 ? 0x7f7fffffu : 0u;
+    __syncthreads();
+    const int i = blockIdx.x * 256 + tid;
+    const bool valid = i < n;
+    int sg = 0;
+    uint32_t v[3] = {0, 0, 0};
+    if (valid) {
+        const Float4 p = posm[i];
+        v[0] = __float_as_uint(p.x); v[1] = __float_as_uint(p.y); v[2] = __float_as_uint(p.z);
+        int lo = 0, hi = F;   // largest sg with s_seg[sg] <= i
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_seg[mid] <= i) lo = mid; else hi = mid;
+        }
+        sg = lo;
+    }
+    const int sg0 = __builtin_amdgcn_readfirstlane(sg);
+    if (__all(valid && sg == sg0)) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            uint32_t mn = v[k], mx = v[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                mn = min(mn, (uint32_t) __shfl_xor((int) mn, o, 64));
+                mx = max(mx, (uint32_t) __shfl_xor((int) mx, o, 64));
+            }
+            if ((tid & 63) == 0) { atomicMin(&s_box[sg0][k], mn); atomicMax(&s_box[sg0][3 + k], mx); }
+        }
+    } else if (valid) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { atomicMin(&s_box[sg][k], v[k]); atomicMax(&s_box[sg][3 + k], v[k]); }
+    }
+    __syncthreads();
+    if (tid < F * 6) {
+        const int sl = tid / 6, k = tid % 6;
+        const uint32_t b = s_box[sl][k];
+        uint32_t *dst = reinterpret_cast<uint32_t *>(rec + (size_t) sl * LET_REC + k);
+        if (k < 3) { if (b != 0x7f7fffffu) atomicMin(dst, b); }
+        else if (s_box[sl][k - 3] != 0x7f7fffffu) atomicMax(dst, b);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Export of the locally-essential tree.  A remote domain d is described by its frontier
+// boxes; the opening criterion of this tree's node a with respect to d is the traversal's
+// own  size^2 / dist^2 < theta^2  with dist = the smallest distance from any of d's boxes to
+// a's centre of mass -- never larger than the distance from any body of d (every body lies in
+// one of the boxes), so whatever passes here would pass for every group of d as well.
+// k_let_mask evaluates the criterion once per (inner node, domain) into a bit mask; the
+// enclosing box of the domain is tried first (it passes => every box passes).
+// k_let_emit, one thread per (node, domain): a node is REACHED iff none of its ancestors
+// passes; a reached node exports (com, mass) if it passes itself, all its particles if it is
+// a leaf, nothing otherwise (its children decide).  No stack, no queue; output slots come
+// from one atomic per workgroup and domain.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_let_mask(const Counts *counts,
+                                                  const Float4 *__restrict__ nodeA,
+                                                  const NodeB *__restrict__ nodeB,
+                                                  const float *__restrict__ frontiers, int ndom,
+                                                  int T, int skip, float theta,
+                                                  uint32_t *__restrict__ mask)
+{
+    extern __shared__ float s_geo[];   // [ndom][T][6] boxes, then [ndom][6] enclosing boxes
+    float *s_hull = s_geo + (size_t) ndom * T * 6;
+    const int tid = threadIdx.x;
+    for (int j = tid; j < ndom * T * 6; j += 256)
+        s_geo[j] = frontiers[(size_t) (j / 6) * LET_REC + (j % 6)];
+    __syncthreads();
+    for (int j = tid; j < ndom * 6; j += 256) {
+        const int d = j / 6, k = j % 6;
+        float v = s_geo[(size_t) d * T * 6 + k];
+        for (int b = 1; b < T; ++b) {
+            const float w = s_geo[((size_t) d * T + b) * 6 + k];
+            const bool empty = s_geo[((size_t) d * T + b) * 6] > 1.0e38f;
+            if (!empty) v = k < 3 ? fminf(v, w) : fmaxf(v, w);
+        }
+        s_hull[j] = v;
+    }
+    __syncthreads();
+    const int n_oct = counts->n_oct;
+    const float th2 = theta * theta;
+    for (int o = blockIdx.x * 256 + tid; o < n_oct; o += gridDim.x * 256) {
+        const NodeB B = nodeB[o];
+        uint32_t bits = 0;
+        if (!(B.meta & NODE_LEAF)) {
+            const Float4 A = nodeA[o];
+            const float sz2 = B.size * B.size;
+            for (int d = 0; d < ndom; ++d) {
+                if (d == skip) continue;
+                bool pass = __fdiv_rn(sz2, box_dist_sq(s_hull + 6 * d, A.x, A.y, A.z)) < th2;
+                if (!pass) {
+                    float dmin = 3.0e38f;
+                    const float *g = s_geo + (size_t) d * T * 6;
+                    for (int b = 0; b < T; ++b) dmin = fminf(dmin, box_dist_sq(g + 6 * b, A.x, A.y, A.z));
+                    pass = __fdiv_rn(sz2, dmin) < th2;
+                }
+                bits |= (pass ? 1u : 0u) << d;
+            }
+        }
+        mask[o] = bits;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_let_emit(
     const Counts *counts, const Float4 *__restrict__ nodeA, const NodeB *__restrict__ nodeB,
     const int32_t *__restrict__ o_parent, const Float4 *__restrict__ posm,
-    const float *__restrict__ boxes, float theta, Float4 *__restrict__ out, int cap,
+    const uint32_t *__restrict__ mask, int skip, Float4 *__restrict__ out, int cap,
     uint32_t *__restrict__ out_count)
 {
     __shared__ uint32_t s_scan[5];
     __shared__ uint32_t s_base;
     const int n_oct = counts->n_oct;
-    const int box = blockIdx.y;
-    const float *bx = boxes + 6 * box;
-    const float th2 = theta * theta;
+    const int dom = blockIdx.y;
+    if (dom == skip) return;
     const int o = blockIdx.x * 256 + threadIdx.x;
-    auto passes = [&](int a) -> bool {
-        const Float4 A = nodeA[a];
-        const float sz = nodeB[a].size;
-        return __fdiv_rn(sz * sz, box_dist_sq(bx, A.x, A.y, A.z)) < th2;
-    };
     uint32_t cnt = 0;
-    bool leaf = false, whole = false;
+    bool whole = false;
     NodeB me{};
     if (o < n_oct) {
         bool reached = true;
         for (int a = o_parent[o]; a >= 0; a = o_parent[a])
-            if (passes(a)) { reached = false; break; }
+            if ((mask[a] >> dom) & 1u) { reached = false; break; }
         if (reached) {
             me = nodeB[o];
-            leaf = (me.meta & NODE_LEAF) != 0u;
-            if (leaf) cnt = (uint32_t) me.count;
-            else if (passes(o)) { whole = true; cnt = 1; }
+            if (me.meta & NODE_LEAF) cnt = (uint32_t) me.count;
+            else if ((mask[o] >> dom) & 1u) { whole = true; cnt = 1; }
         }
     }
     uint32_t tot;
     const uint32_t excl = block_excl_scan_u32<4>(cnt, s_scan, &tot);
-    if (threadIdx.x == 0) s_base = tot ? atomicAdd(&out_count[box], tot) : 0u;
+    if (threadIdx.x == 0) s_base = tot ? atomicAdd(&out_count[dom], tot) : 0u;
     __syncthreads();
     if (cnt == 0) return;
     const size_t pos = (size_t) s_base + excl;
-    if (pos + cnt > (size_t) cap) return;  // over capacity: the host sees out_count > cap
-    Float4 *dst = out + (size_t) box * cap + pos;
+    if (pos + cnt > (size_t) cap) return;  // over capacity: the caller sees out_count > cap
+    Float4 *dst = out + (size_t) dom * cap + pos;
     if (whole) dst[0] = nodeA[o];
     else
         for (int k = 0; k < me.count; ++k) dst[k] = posm[me.first + k];
@@ -117,6 +299,92 @@ __global__ __launch_bounds__(256) void k_unpack_sources(int n, const Float4 *__r
     id[i] = (uint32_t) i;
 }
 
+// ---------------------------------------------------------------------------
+// Re-balancing of a Morton-range decomposition: positions of query keys in the handle's sorted
+// keys (histograms of key prefixes and the cut positions of the splitters are differences of
+// these), and the 44-byte particle record that migrates between domains:
+// x, y, z, vx, vy, vz, m, ax, ay, az, id.
+// ---------------------------------------------------------------------------
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_key_lower_bound(const KeyT *__restrict__ sorted, int n,
+                                                         const uint64_t *__restrict__ queries, int nq,
+                                                         int key_bits, int32_t *__restrict__ out)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= nq) return;
+    const uint64_t q = queries[j];
+    int lo = 0, hi = n;   // first index whose key is >= q; a query of 2^key_bits is "past the end"
+    if ((q >> key_bits) != 0) lo = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((uint64_t) sorted[mid] < q) lo = mid + 1; else hi = mid;
+    }
+    out[j] = lo;
+}
+
+constexpr int MIG_WORDS = 11;
+
+__global__ __launch_bounds__(256) void k_pack_particles(
+    int n, const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z,
+    const float *__restrict__ vx, const float *__restrict__ vy, const float *__restrict__ vz,
+    const float *__restrict__ m, const float *__restrict__ ax, const float *__restrict__ ay,
+    const float *__restrict__ az, const uint32_t *__restrict__ id, float *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float *r = out + (size_t) i * MIG_WORDS;
+    r[0] = x[i]; r[1] = y[i]; r[2] = z[i]; r[3] = vx[i]; r[4] = vy[i]; r[5] = vz[i]; r[6] = m[i];
+    r[7] = ax[i]; r[8] = ay[i]; r[9] = az[i]; r[10] = __uint_as_float(id[i]);
+}
+
+// The accelerations ride in the half-step velocity arrays (dead between two steps) so that
+// the permute of the following sort carries them along.
+__global__ __launch_bounds__(256) void k_unpack_particles(
+    int n, const float *__restrict__ in, float *__restrict__ x, float *__restrict__ y,
+    float *__restrict__ z, float *__restrict__ vx, float *__restrict__ vy, float *__restrict__ vz,
+    float *__restrict__ m, float *__restrict__ hx, float *__restrict__ hy, float *__restrict__ hz,
+    uint32_t *__restrict__ id)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float *r = in + (size_t) i * MIG_WORDS;
+    x[i] = r[0]; y[i] = r[1]; z[i] = r[2]; vx[i] = r[3]; vy[i] = r[4]; vz[i] = r[5]; m[i] = r[6];
+    hx[i] = r[7]; hy[i] = r[8]; hz[i] = r[9]; id[i] = __float_as_uint(r[10]);
+}
+
+hipError_t launch_key_lower_bound(Sim *s, const uint64_t *queries_dev, int nq, int32_t *out_dev)
+{
+    if (nq <= 0) return hipSuccess;
+    const int kb = s->key_bytes == 4 ? 30 : 63;
+    if (s->key_bytes == 4)
+        hipLaunchKernelGGL(k_key_lower_bound<uint32_t>, dim3((nq + 255) / 256), dim3(256), 0, s->stream,
+                           (const uint32_t *) s->keys[s->sorted_buf], s->n, queries_dev, nq, kb, out_dev);
+    else
+        hipLaunchKernelGGL(k_key_lower_bound<uint64_t>, dim3((nq + 255) / 256), dim3(256), 0, s->stream,
+                           (const uint64_t *) s->keys[s->sorted_buf], s->n, queries_dev, nq, kb, out_dev);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_particles(Sim *s, float *out)
+{
+    const int c = s->cur;
+    if (s->n < 1) return hipSuccess;
+    hipLaunchKernelGGL(k_pack_particles, dim3((s->n + 255) / 256), dim3(256), 0, s->stream, s->n, s->x[c],
+                       s->y[c], s->z[c], s->vx[c], s->vy[c], s->vz[c], s->m[c], s->ax, s->ay, s->az,
+                       s->id[c], out);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack_particles(Sim *s, const float *in, int n)
+{
+    const int c = s->cur;
+    if (n < 1) return hipSuccess;
+    hipLaunchKernelGGL(k_unpack_particles, dim3((n + 255) / 256), dim3(256), 0, s->stream, n, in, s->x[c],
+                       s->y[c], s->z[c], s->vx[c], s->vy[c], s->vz[c], s->m[c], s->vhx[c], s->vhy[c],
+                       s->vhz[c], s->id[c]);
+    return hipGetLastError();
+}
+
 hipError_t launch_bbox(Sim *s, uint32_t *box_dev)
 {
     hipLaunchKernelGGL(k_bbox, dim3(std::min((s->n + 255) / 256, 1024)), dim3(256), 0, s->stream,
@@ -124,14 +392,30 @@ hipError_t launch_bbox(Sim *s, uint32_t *box_dev)
     return hipGetLastError();
 }
 
-hipError_t launch_let_export(Sim *s, const float *boxes_dev, int nboxes, Float4 *out, int cap,
-                             uint32_t *out_count)
+// records_dev: T * LET_REC floats.  seg: LET_MAX_T + 2 ints of scratch.
+hipError_t launch_frontier(Sim *s, float *records_dev, int T)
 {
-    // grid.x from the host-known upper bound of the node count (2n); surplus threads exit
+    hipLaunchKernelGGL(k_frontier_select, dim3(1), dim3(256), 0, s->stream, s->counts, s->n, T,
+                       s->nodeB, s->nodeA, s->o_pb, s->o_pe, records_dev, s->let_seg);
+    hipLaunchKernelGGL(k_frontier_bbox, dim3((s->n + 255) / 256), dim3(256), 0, s->stream, s->n,
+                       s->posm, s->let_seg, records_dev);
+    return hipGetLastError();
+}
+
+// frontiers_dev: ndom * T records (ndom <= LET_MASK_DOMAINS); out: [ndom][cap] records;
+// out_count[ndom] is zeroed here.  Domain `skip` (the caller's own, -1 = none) gets nothing.
+hipError_t launch_let_export(Sim *s, const float *frontiers_dev, int ndom, int T, int skip,
+                             Float4 *out, int cap, uint32_t *out_count)
+{
+    hipError_t e = hipMemsetAsync(out_count, 0, (size_t) ndom * sizeof(uint32_t), s->stream);
+    if (e != hipSuccess) return e;
+    // grids from the host-known upper bound of the node count (2n); surplus threads exit
     const int gx = (2 * s->n + 255) / 256;
-    hipLaunchKernelGGL(k_let_export, dim3(gx, nboxes), dim3(256), 0, s->stream, s->counts,
-                       s->nodeA, s->nodeB, s->o_parent, s->posm, boxes_dev, s->p.theta, out, cap,
-                       out_count);
+    const size_t lds = ((size_t) ndom * T * 6 + (size_t) ndom * 6) * sizeof(float);
+    hipLaunchKernelGGL(k_let_mask, dim3(std::min(gx, 2048)), dim3(256), lds, s->stream, s->counts,
+                       s->nodeA, s->nodeB, frontiers_dev, ndom, T, skip, s->p.theta, s->let_mask);
+    hipLaunchKernelGGL(k_let_emit, dim3(gx, ndom), dim3(256), 0, s->stream, s->counts, s->nodeA,
+                       s->nodeB, s->o_parent, s->posm, s->let_mask, skip, out, cap, out_count);
     return hipGetLastError();
 }
 

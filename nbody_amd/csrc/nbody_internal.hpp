@@ -20,6 +20,9 @@ constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 16;                      // elements per thread in compaction tiles
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 constexpr int LET_MAX_BOXES = 256;
+constexpr int LET_MAX_T = 32;                       // frontier records a domain advertises
+constexpr int LET_REC = 12;                         // floats per frontier record
+constexpr int LET_MASK_DOMAINS = 32;                // remote domains per export launch (mask bits)
 constexpr int TRAV_WAVES = 4;                       // groups (waves) per traversal workgroup
 constexpr int TRAV_STACK = 512;                     // LDS inner-node stack entries per wave
 constexpr int TRAV_LEAF_STACK = 544;                // LDS leaf stack entries per wave
@@ -159,8 +162,12 @@ struct Sim {
     int trav_sum_slot[2] = {0, 0}, trav_prev_groups[2] = {0, 0};
     float *pot = nullptr;            // per-body potential sums (allocated by the first energy call)
     // LET exchange scratch
-    float *let_boxes = nullptr;      // [64][6] device copy of the remote boxes
-    uint32_t *let_counts = nullptr;  // [64] + 6 words of bounding box
+    float *let_boxes = nullptr;      // [LET_MAX_BOXES][LET_REC] device copy of caller-given boxes
+    uint32_t *let_counts = nullptr;  // [LET_MAX_BOXES] + 6 words of bounding box
+    uint32_t *let_mask = nullptr;    // [2n] per node: domains whose opening criterion it passes
+    int32_t *let_seg = nullptr;      // [LET_MAX_T + 2] first particles of the frontier nodes, count
+    float *let_frontier = nullptr;   // [LET_MAX_T][LET_REC] frontier of nbody_let_frontier
+    hipEvent_t ev_ready = nullptr;   // marks this handle's queued work for a waiting handle
 
     // caller-owned viewer buffers [pos.x, pos.y, pos.z, com.x, com.y, com.z, node_size] (nullable)
     float *ext[7]{};
@@ -215,9 +222,21 @@ hipError_t launch_traverse_from(Sim *bodies, Sim *sources, bool accumulate);
 hipError_t launch_potential(Sim *s);                        // -> s->pot
 hipError_t launch_export_view(Sim *s);                      // positions + node COM/size -> ext[]
 hipError_t launch_bbox(Sim *s, uint32_t *box_dev);
-hipError_t launch_let_export(Sim *s, const float *boxes_dev, int nboxes, Float4 *out, int cap,
-                             uint32_t *out_count);
+hipError_t launch_frontier(Sim *s, float *records_dev, int T);
+hipError_t launch_let_export(Sim *s, const float *frontiers_dev, int ndom, int T, int skip,
+                             Float4 *out, int cap, uint32_t *out_count);
 hipError_t launch_unpack_sources(Sim *s, const Float4 *src, int n);
+hipError_t launch_key_lower_bound(Sim *s, const uint64_t *queries_dev, int nq, int32_t *out_dev);
+hipError_t launch_pack_particles(Sim *s, float *out);              // 11 words per particle
+hipError_t launch_unpack_particles(Sim *s, const float *in, int n);
+// Sort + build over the n particles k_unpack_particles has just put into the current buffers
+// (accelerations in the half-step velocity arrays); everything on the handle's stream.
+int install_particles_dev(Sim *s, int n);
+// Host sampler of the initial conditions for particle indices [first, first + count) of a set of
+// n_total particles.
+int sample_ic_range(int kind, long long first, int count, long long n_total, uint64_t seed, float domain,
+                    float gravity, float p0, float p1, float *x, float *y, float *z, float *vx,
+                    float *vy, float *vz, float *m);
 
 // ---- on-device reductions (k_reduce.hip) ----
 size_t reduce_scratch_bytes(int blocks, int k);

@@ -13,14 +13,18 @@ the two exchange steps the step path has when it is spread over the GPUs of a no
   flight while the current one is being summed), each rank accumulating the accelerations of
   its own bodies.  No reduction is needed.
 
-* LetStepper -- Barnes-Hut step with DOMAIN DECOMPOSITION.  Every rank owns a fixed subset of
-  the particles (one box of an orthogonal recursive bisection of the initial conditions), builds a tree over
-  them only and traverses it; what its bodies need from the other domains arrives as a
-  locally-essential tree: an all-gather of the P bounding boxes (24 bytes each), then ONE
-  all-to-all of (x,y,z,m) records -- the centres of mass of remote nodes the whole box may
-  approximate, and the particles of remote leaves it may not.  A second tree is built over
-  the received records and traversed for the own bodies.  Memory, build and traversal all
-  scale with N/P; the exchanged volume is a surface term.
+* DomainDecomposition / LetStepper -- Barnes-Hut step with DOMAIN DECOMPOSITION along the
+  Morton curve.  Every rank owns the particles of one contiguous range of Morton keys (ranges
+  re-drawn now and then from an all-gathered histogram of key prefixes, particles migrated by
+  an all-to-all), builds a tree over them only and traverses it; what its bodies need from the
+  other domains arrives as a locally-essential tree: an all-gather of every domain's top-of-
+  tree nodes (boxes, centres of mass, masses, sizes), then ONE all-to-all of (x,y,z,m) records
+  -- the centres of mass of remote nodes that pass the opening criterion against the nearest
+  box of the receiving domain, and the particles of remote leaves that do not.  A second tree
+  is built over the received records and traversed for the own bodies.  Memory, build and
+  traversal scale with N/P; the exchanged volume is a surface term.  DomainDecomposition
+  drives the native implementation (nbody_dd_*, csrc/dd.hip) with torch.distributed
+  collectives; LetStepper is the same choreography over an injected backend (CPU tests).
 
 The compute itself is injected (`backend` / `tile_kernel`), so the same choreography runs on
 GPUs through libnbody_mi355.so and in the CPU tests through the host oracle.
@@ -92,96 +96,152 @@ class ShardedTraversal:
             torch.cuda.current_stream(t.device).synchronize()
 
 
+DD_BINS = 4096      # histogram bins per refinement round of the key-range re-balancing
+DD_BIN_BITS = 12
+DD_SLACK = 0.005    # a cut may miss its target by this share of a domain's particles
+
+
+def morton_splitters(lower_bounds, gather_sum, parts, key_bits, slack_share=DD_SLACK):
+    """Key-range splitters of `parts` domains of (nearly) equal particle count: the protocol of
+    nbody_dd_rebalance (csrc/dd.hip) with the collectives injected.
+      lower_bounds(q)  positions of the uint64 query keys q in this rank's SORTED keys
+      gather_sum(a)    element-wise sum over all ranks of the uint64 array a
+    Round 1 histograms the top 12 key bits (4096 bins) and takes, for every cut, the coarsest
+    bin edge within the slack of its target; a cut that no edge meets is refined, round after
+    round, with a 4096-bin histogram of the next 12 bits of the bin that holds its target.  Returns
+    (splitters uint64[parts + 1], total particle count); splitters[parts] = 2^key_bits."""
+    import numpy as np
+    import nbody_amd as nb
+    q = np.arange(DD_BINS + 1, dtype=np.uint64) << np.uint64(key_bits - DD_BIN_BITS)
+    lb = np.asarray(lower_bounds(q), np.int64)
+    hist = np.asarray(gather_sum(np.diff(lb).astype(np.uint64)), np.uint64)
+    total = int(hist.sum())
+    if total == 0:
+        raise RuntimeError("re-balance: no particles anywhere")
+    slack = int(slack_share * total / parts)
+    edge, bin_ = nb.choose_edges(hist, parts, slack)
+    P1 = np.concatenate([[0], np.cumsum(hist.astype(object))])
+    split = [0] * (parts + 1)
+    split[parts] = 1 << key_bits
+    pending = []          # (cut, prefix of the bin that holds its target, particles before that bin)
+    for k in range(1, parts):
+        if edge[k - 1] >= 0:
+            split[k] = int(edge[k - 1]) << (key_bits - DD_BIN_BITS)
+        else:
+            pending.append((k, int(bin_[k - 1]), int(P1[int(bin_[k - 1])])))
+    bits = DD_BIN_BITS
+    while pending:
+        nb_ = min(DD_BIN_BITS, key_bits - bits)
+        nbins, sh = 1 << nb_, key_bits - bits - nb_
+        q2 = np.array([((prefix << nb_) + j) << sh for _, prefix, _ in pending for j in range(nbins + 1)],
+                      dtype=np.uint64)
+        lb2 = np.asarray(lower_bounds(q2), np.int64).reshape(len(pending), nbins + 1)
+        h2 = np.asarray(gather_sum(np.diff(lb2, axis=1).astype(np.uint64).reshape(-1)), np.uint64)
+        h2 = h2.reshape(len(pending), nbins)
+        nxt = []
+        for (k, prefix, base), h in zip(pending, h2):
+            target = total * k // parts
+            j = nb.refine_edge(h, base, target, slack, prefix << nb_, bits + nb_)
+            cum = base + int(h[:j].sum())
+            if abs(cum - target) <= slack or bits + nb_ == key_bits:
+                split[k] = ((prefix << nb_) + j) << sh
+            else:               # descend into the sub-bin that holds the target
+                before, b = base, 0
+                while b + 1 < nbins and before + int(h[b]) <= target:
+                    before += int(h[b])
+                    b += 1
+                nxt.append((k, (prefix << nb_) + b, before))
+        pending = nxt
+        bits += nb_
+    for k in range(1, parts + 1):
+        split[k] = max(split[k], split[k - 1])
+    return np.array(split, dtype=np.uint64), total
+
+
 class LetStepper:
-    """backend must provide:
+    """Domain decomposition along the Morton curve with a locally-essential-tree exchange, the
+    choreography of nbody_dd_step / nbody_dd_rebalance (csrc/dd.hip) written against an
+    injected backend, so that it runs without a GPU (CPU tests: host oracle as the backend,
+    gloo collectives).  On GPUs use DomainDecomposition, which drives the native code.
+    backend must provide:
+        device                        torch device of the exchanged tensors
+        key_bits                      30 or 63
         update()                      kick-drift, sort, build of the own tree (no forces yet)
-        bbox()                        6 floats (lo xyz, hi xyz) of the own particles
-        let_export(boxes)             boxes: (k, 6) float32 array -> list of k (cnt_i, 4)
-                                      float32 torch tensors on the backend's device
-        begin_local_forces()          start the own-tree traversal; may return before it is
-                                      done, so that it runs while the records are exchanged
+        frontier(T)                   (T, 12) float32 tensor: top-of-tree records (lo xyz, hi xyz,
+                                      com xyz, mass, size, count), empty records lo = 3e38
+        let_export(frontiers, me)     frontiers (W, T, 12) tensor -> list of W (cnt_r, 4) float32
+                                      tensors of (x,y,z,m) records (entry `me` empty)
+        begin_local_forces()          own-tree traversal (may return before it is done)
         add_remote(records)           (cnt, 4) tensor: build a tree over it, add its attraction
         finish_step()                 velocity kick
-        device                        torch device of the exchanged tensors
+      for rebalance():
+        key_lower_bounds(q)           positions of uint64 keys in the own sorted keys
+        get_particles()/set_particles(dict)   x,y,z,vx,vy,vz,m,ax,ay,az float32, id uint32,
+                                      in the CURRENT (key-sorted) order
     """
 
-    def __init__(self, backend, process_group=None):
+    def __init__(self, backend, process_group=None, records_per_domain=32):
         self.b = backend
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
+        self.T = records_per_domain
         self.last_sent = 0
         self.last_received = 0
+        self.splitters = None
 
     def step(self):
         b, W, me = self.b, self.world, self.rank
         b.update()
         dev = b.device
-        box = torch.as_tensor(b.bbox(), dtype=torch.float32).to(dev)
-        boxes = torch.empty(W * 6, dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(boxes, box, group=self.pg)
-        boxes = boxes.view(W, 6)
-        others = [r for r in range(W) if r != me]
-        recs = b.let_export(boxes.cpu().numpy()[others]) if others else []
+        if W == 1:
+            b.begin_local_forces()
+            b.finish_step()
+            return
+        fr = b.frontier(self.T).to(dev).contiguous()
+        allfr = torch.empty(W * self.T * 12, dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(allfr, fr.view(-1), group=self.pg)
+        recs = b.let_export(allfr.view(W, self.T, 12), me)
         b.begin_local_forces()
-        send_rows = [0] * W
-        for r, t in zip(others, recs):
-            send_rows[r] = int(t.shape[0])
+        send_rows = [0 if r == me else int(t.shape[0]) for r, t in enumerate(recs)]
         sc = torch.tensor(send_rows, dtype=torch.int64, device=dev)
         rc = torch.empty_like(sc)
         dist.all_to_all_single(rc, sc, group=self.pg)
         recv_rows = [int(v) for v in rc.cpu()]
-        send = torch.cat(recs) if recs else torch.empty(0, 4, dtype=torch.float32, device=dev)
+        parts = [t.to(dev) for r, t in enumerate(recs) if r != me and t.shape[0]]
+        send = torch.cat(parts) if parts else torch.empty(0, 4, dtype=torch.float32, device=dev)
         recv = torch.empty(sum(recv_rows), 4, dtype=torch.float32, device=dev)
         dist.all_to_all_single(recv, send.contiguous(), recv_rows, send_rows, group=self.pg)
-        if recv.is_cuda:  # the library works on its own stream: finish RCCL before the build
-            torch.cuda.current_stream(recv.device).synchronize()
         self.last_sent, self.last_received = sum(send_rows), sum(recv_rows)
         b.add_remote(recv)
         b.finish_step()
 
-    def rebalance(self, sample=4096, seed=0, weighted=False):
-        """Re-draws the domains and migrates particles (call between steps, every few hundred:
-        it goes through host memory).  Every rank contributes `sample` of its positions; all
-        ranks bisect the gathered sample identically (orb_cuts), classify their particles and
-        exchange them with one all-to-all.  Requires backend.get_particles() -> dict of host
-        arrays (x,y,z,vx,vy,vz,m,ax,ay,az float32; id uint32) and backend.set_particles(dict).
-        weighted: the cuts equalise WORK instead of particle counts when the backend has
-        work_weights() -> one float per particle (order of get_particles()): the number of
-        sources its group interacted with in the last force evaluation, own and imported tree.
-        A sampled particle stands for n/sample particles of its rank, so its weight is scaled
-        by that.  Off by default: on the sphere and Plummer workloads equal counts already
-        balance the interaction counts to 3 %, less than the noise of a sampled weighting.
-        Returns the number of particles this rank gave away."""
+    def _gather_sum(self, a):
+        import numpy as np
+        t = torch.from_numpy(np.ascontiguousarray(a, np.uint64).view(np.int64).copy()).to(self.b.device)
+        dist.all_reduce(t, group=self.pg)
+        return t.cpu().numpy().view(np.uint64)
+
+    def rebalance(self):
+        """Re-draws the domains as contiguous Morton-key ranges of (nearly) equal particle
+        counts (morton_splitters) and migrates the particles with one all-to-all of 11-word
+        records.  Returns the number of particles this rank gave away."""
         import numpy as np
         b, W, me = self.b, self.world, self.rank
-        work = b.work_weights() if weighted and hasattr(b, "work_weights") else None
+        split, _ = morton_splitters(b.key_lower_bounds, self._gather_sum, W, b.key_bits)
+        self.splitters = split
+        if W == 1:
+            return 0
         st = b.get_particles()
         n = len(st["x"])
-        pos = np.stack([st["x"], st["y"], st["z"]], 1)
-        rng = np.random.default_rng(seed * 1000003 + me)
-        pick = rng.choice(n, size=sample, replace=n < sample)
-        rec4 = np.empty((sample, 4), np.float32)
-        rec4[:, :3] = pos[pick]
-        rec4[:, 3] = (np.ones(sample) if work is None else np.asarray(work, np.float64)[pick]) * (n / sample)
-        mine = torch.from_numpy(rec4.reshape(-1))
-        allp = torch.empty(W * sample * 4, dtype=torch.float32)
-        if b.device.type == "cuda":     # RCCL moves device memory only
-            g = allp.to(b.device)
-            dist.all_gather_into_tensor(g, mine.to(b.device), group=self.pg)
-            allp = g.cpu()
-        else:
-            dist.all_gather_into_tensor(allp, mine, group=self.pg)
-        allp = allp.numpy().reshape(-1, 4)
-        cuts = orb_cuts(allp[:, :3], W, allp[:, 3].astype(np.float64), grid=getattr(b, "grid", None))
-        dest = orb_assign(cuts, pos)
-        order = np.argsort(dest, kind="stable")
-        send_rows = np.bincount(dest, minlength=W).tolist()
+        lb = np.asarray(b.key_lower_bounds(split), np.int64)
+        lb[0], lb[W] = 0, n
+        send_rows = np.diff(lb).tolist()
         names = ("x", "y", "z", "vx", "vy", "vz", "m", "ax", "ay", "az")
         rec = np.empty((n, 11), np.float32)
         for k, name in enumerate(names):
-            rec[:, k] = st[name][order]
-        rec[:, 10] = st["id"][order].view(np.float32)          # ids ride along bit for bit
+            rec[:, k] = st[name]
+        rec[:, 10] = st["id"].astype(np.uint32).view(np.float32)   # ids ride along bit for bit
         sc = torch.tensor(send_rows, dtype=torch.int64, device=b.device)
         rc = torch.empty_like(sc)
         dist.all_to_all_single(rc, sc, group=self.pg)
@@ -196,102 +256,140 @@ class LetStepper:
         return n - send_rows[me]
 
 
-def snap_to_cells(lo, hi, grid):
-    """The coordinate in [lo, hi] that is a boundary of the coarsest Morton cells: grid =
-    (domain_size, bits per axis); cell q of an axis is [q, q+1) * domain / (2^bits - 1), the
-    quantisation of the library's keys.  A domain cut a hair beside a coarse cell boundary
-    leaves a thin slab of the domain's particles on the far side of it; in Morton order they
-    form groups that are spread over the whole cut face, whose source lists are several times
-    the mean (measured: 27 k against 7 k) and whose waves outlast the traversal.  None (no
-    cell boundary inside) leaves the cut where it is."""
-    import math
-    domain, bits = grid
-    scale = ((1 << bits) - 1) / float(domain)
-    tlo, thi = math.ceil(lo * scale), math.floor(hi * scale)
-    if tlo > thi:
-        return None
-    for p in range(bits, -1, -1):
-        m = -(-tlo >> p) << p          # smallest multiple of 2^p that is >= tlo
-        if m <= thi:
-            return m / scale
-    return None
+class TorchComm:
+    """struct nbody_comm over torch.distributed: the two collectives nbody_dd_* needs, on raw
+    device pointers, enqueued on the hipStream_t the library passes (made torch's current
+    stream for the call, so RCCL orders itself after the kernels already queued there and the
+    kernels queued afterwards wait for it; the host does not wait).  via_host = True stages
+    through host memory (gloo, or several ranks sharing one GPU in tests)."""
+
+    class _Raw:
+        def __init__(self, ptr, nbytes):
+            self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1",
+                                             "data": (ptr, False), "version": 2}
+
+    def __init__(self, device, process_group=None, via_host=False):
+        import ctypes as C
+        import nbody_amd as nb
+        self.device = torch.device(device)
+        self.pg = process_group
+        self.via_host = via_host
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.error = None
+        self._ag = nb.CComm.ALL_GATHER(self._all_gather)
+        self._a2a = nb.CComm.ALL_TO_ALL(self._all_to_all)
+        self.c = nb.CComm(self.rank, self.size, None, self._ag, self._a2a)
+
+    def _t(self, ptr, nbytes):
+        if not nbytes or not ptr:
+            return torch.empty(0, dtype=torch.uint8, device=self.device)
+        return torch.as_tensor(self._Raw(ptr, nbytes), device=self.device)
+
+    def _stream(self, stream):
+        return torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.device))
+
+    def _all_gather(self, ctx, send, recv, nbytes, stream):
+        try:
+            with self._stream(stream):
+                s, r = self._t(send, nbytes), self._t(recv, nbytes * self.size)
+                if self.via_host:
+                    hr = torch.empty(nbytes * self.size, dtype=torch.uint8)
+                    dist.all_gather_into_tensor(hr, s.cpu(), group=self.pg)
+                    r.copy_(hr)
+                else:
+                    dist.all_gather_into_tensor(r, s, group=self.pg)
+            return 0
+        except Exception as e:      # never let an exception cross the C boundary
+            self.error = e
+            return 1
+
+    def _all_to_all(self, ctx, send, sbytes, soff, recv, rbytes, roff, stream):
+        try:
+            W = self.size
+            sb, so = [int(sbytes[r]) for r in range(W)], [int(soff[r]) for r in range(W)]
+            rb, ro = [int(rbytes[r]) for r in range(W)], [int(roff[r]) for r in range(W)]
+            with self._stream(stream):
+                sbuf = self._t(send, max((o + b for o, b in zip(so, sb)), default=0))
+                rbuf = self._t(recv, max((o + b for o, b in zip(ro, rb)), default=0))
+                packed_in = all(so[r] == sum(sb[:r]) for r in range(W))
+                packed_out = all(ro[r] == sum(rb[:r]) for r in range(W))
+                inp = sbuf[:sum(sb)] if packed_in else torch.cat([sbuf[o:o + b] for o, b in zip(so, sb)])
+                out = rbuf[:sum(rb)] if packed_out else torch.empty(sum(rb), dtype=torch.uint8, device=self.device)
+                if self.via_host:
+                    ho = torch.empty(sum(rb), dtype=torch.uint8)
+                    dist.all_to_all_single(ho, inp.cpu(), rb, sb, group=self.pg)
+                    out.copy_(ho)
+                else:
+                    dist.all_to_all_single(out, inp.contiguous(), rb, sb, group=self.pg)
+                if not packed_out:
+                    at = 0
+                    for o, b in zip(ro, rb):
+                        rbuf[o:o + b].copy_(out[at:at + b])
+                        at += b
+            return 0
+        except Exception as e:
+            self.error = e
+            return 1
 
 
-def orb_cuts(points, parts, weights=None, grid=None, slack=0.005):
-    """Orthogonal recursive bisection of `points` (k, 3) into `parts` boxes covering all of
-    space: nested tuples (axis, threshold, parts_left, left, right), leaves = None.  Every cut
-    goes across the longest axis of the piece at the quantile -- of the point count, or of
-    `weights` (k,) when given -- that matches the ranks on either side; with equal weights it
-    is the rule of domain_slices.  With grid = (domain_size, bits) a cut moves to the
-    coarsest Morton cell boundary within `slack` of the piece's points (snap_to_cells)."""
-    import numpy as np
-    pts = np.asarray(points, np.float64)
-    w = np.ones(len(pts)) if weights is None else np.asarray(weights, np.float64)
-    if parts == 1:
-        return None
-    left = parts // 2
-    axis = int(np.argmax(pts.max(0) - pts.min(0))) if len(pts) else 0
-    if len(pts) >= 2:
-        order = np.argsort(pts[:, axis], kind="stable")
-        v = pts[order, axis]
-        cw = np.cumsum(w[order])
-        # first k points carry (just under) left/parts of the weight; counts when w == 1
-        k = int(np.searchsorted(cw, cw[-1] * left / parts, side="right"))
-        k = min(max(k, 1), len(v) - 1)
-        thr = 0.5 * (v[k - 1] + v[k])
-        if grid is not None:
-            d = int(slack * len(v))
-            snapped = snap_to_cells(v[max(k - 1 - d, 0)], v[min(k + d, len(v) - 1)], grid)
-            if snapped is not None:
-                thr = snapped
-    else:
-        thr = float(pts[0, axis]) if len(pts) else 0.0
-    m = pts[:, axis] < thr
-    return (axis, float(thr), left, orb_cuts(pts[m], left, w[m], grid, slack),
-            orb_cuts(pts[~m], parts - left, w[~m], grid, slack))
+class DomainDecomposition:
+    """nbody_dd_* over a nbody_amd.Simulation: the native multi-GPU step (Morton-range
+    ownership, frontier all-gather, LET all-to-all) with torch.distributed collectives.
+    `sim` holds this rank's particles; create it with head-room (num_points >= the most
+    particles the domain may ever hold)."""
 
+    def __init__(self, sim, device, process_group=None, via_host=False):
+        import ctypes as C
+        import nbody_amd as nb
+        self._nb, self._C = nb, C
+        self.sim = sim
+        self.comm = TorchComm(device, process_group, via_host)
+        self._lib = nb.load_library()
+        self._h = C.c_void_p()
+        rc = self._lib.nbody_dd_create(sim._h, C.byref(self.comm.c), C.byref(self._h))
+        if rc != nb.OK:
+            raise RuntimeError(f"nbody_dd_create failed with status {rc}")
 
-def orb_assign(cuts, pos, first=0):
-    """Domain index of every row of pos (k, 3) under orb_cuts' tree."""
-    import numpy as np
-    pos = np.asarray(pos)
-    out = np.full(len(pos), first, np.int64)
-    if cuts is None or len(pos) == 0:
+    def _check(self, rc):
+        if rc != self._nb.OK:
+            msg = self._lib.nbody_dd_last_error(self._h)
+            raise RuntimeError(f"nbody_dd status {rc}: {msg.decode() if msg else ''}"
+                               + (f" ({self.comm.error!r})" if self.comm.error else ""))
+
+    def spawn(self, kind, n_total, p0=0.0, p1=0.0):
+        self._check(self._lib.nbody_dd_spawn(self._h, kind, n_total, p0, p1))
+
+    def rebalance(self):
+        self._check(self._lib.nbody_dd_rebalance(self._h))
+
+    def step(self):
+        self._check(self._lib.nbody_dd_step(self._h))
+
+    def stats(self):
+        st = self._nb.CDDStats()
+        sp = (self._C.c_uint64 * (self.comm.size + 1))()
+        self._check(self._lib.nbody_dd_get_stats(self._h, self._C.byref(st), sp))
+        out = {k: getattr(st, k) for k, _ in self._nb.CDDStats._fields_}
+        out["splitters"] = [int(v) for v in sp]
         return out
-    axis, thr, left, lo, hi = cuts
-    m = pos[:, axis].astype(np.float64) < thr
-    out[m] = orb_assign(lo, pos[m], first)
-    out[~m] = orb_assign(hi, pos[~m], first + left)
-    return out
 
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.nbody_dd_destroy(self._h)
+            self._h = self._C.c_void_p()
 
-def domain_slices(x, y, z, world, grid=None, slack=0.005):
-    """Index arrays of `world` domains of (nearly) equal particle count with disjoint, tight
-    bounding boxes: orthogonal recursive bisection of the given positions (numpy), each cut
-    across the longest axis of the piece, in the ratio of the ranks on either side.  This is
-    the initial ownership of a LetStepper run.  With grid = (domain_size, bits per axis) a cut
-    moves to the coarsest Morton cell boundary within `slack` of the piece's particles
-    (snap_to_cells); the counts then differ by up to that fraction."""
-    import numpy as np
-    pos = np.stack([np.asarray(a, np.float64) for a in (x, y, z)], 1)
+    def __enter__(self):
+        return self
 
-    def cut(idx, parts):
-        if parts == 1:
-            return [np.sort(idx)]
-        left = parts // 2
-        p = pos[idx]
-        axis = int(np.argmax(p.max(0) - p.min(0)))
-        k = len(idx) * left // parts
-        order = np.argsort(p[:, axis], kind="stable")
-        if grid is not None and 1 <= k < len(idx):
-            v = p[order, axis]
-            d = int(slack * len(v))
-            snapped = snap_to_cells(v[max(k - 1 - d, 0)], v[min(k + d, len(v) - 1)], grid)
-            if snapped is not None:
-                k = int(np.searchsorted(v, snapped, side="left"))   # x < cut goes left
-        return cut(idx[order[:k]], left) + cut(idx[order[k:]], parts - left)
+    def __exit__(self, *exc):
+        self.close()
 
-    return cut(np.arange(len(pos)), world)
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def ring_direct_sum(local_posm: torch.Tensor, tile_kernel, process_group=None):
@@ -366,99 +464,3 @@ class GpuBackend:
 
     def finish_step(self):
         self.sim.finish_step()
-
-
-class GpuLetBackend:
-    """LetStepper backend over two nbody_amd.Simulation handles on one GPU: `sim` holds the
-    own particles, `remote` (created here, grown on demand) the imported records."""
-
-    def __init__(self, sim, device, record_capacity=None, exchange_device=None,
-                 remote_codes_per_leaf=None):
-        import nbody_amd as nb
-        self._nb = nb
-        self.sim = sim
-        self.gpu = torch.device(device)
-        # where the exchanged tensors live: the GPU itself under RCCL; "cpu" lets several
-        # ranks share one GPU over gloo (tests)
-        self.device = torch.device(exchange_device) if exchange_device else self.gpu
-        self.n = sim.params.num_points
-        self.grid = (sim.params.domain_size, sim.params.morton_bits)   # cuts snap to its cells
-        g = sim.params.traversal_group_size
-        sim.set_traversal_range(0, 0)   # update() = build only; forces and kick are driven here
-        self.cap = int(record_capacity or max(4096, self.n // 4))
-        # Leaves are never approximated, and a far region is represented by a handful of records
-        # that would all share one 32-code leaf: small leaves let the opening criterion work on
-        # them (import traversal 2.05 -> 1.35 ms at 8 x 2,097,152 particles).
-        self.remote_codes_per_leaf = int(remote_codes_per_leaf or
-                                         min(8, sim.params.max_num_codes_per_leaf))
-        self._buf = None
-        self.remote = None
-        self._remote_cap = 0
-
-    def update(self):
-        self.sim.update()
-
-    def bbox(self):
-        return self.sim.get_bbox()
-
-    def let_export(self, boxes):
-        k = len(boxes)
-        while True:
-            if self._buf is None or self._buf.shape[0] < k or self._buf.shape[1] < self.cap:
-                self._buf = torch.empty(k, self.cap, 4, dtype=torch.float32, device=self.gpu)
-            try:
-                counts = self.sim.let_export(boxes, self._buf.data_ptr(), self._buf.shape[1])
-                break
-            except self._nb.CapacityError as e:
-                self.cap = int(max(e.counts) * 1.25) + 1024
-                self._buf = None
-        return [self._buf[i, :int(c)].to(self.device) for i, c in enumerate(counts)]
-
-    def begin_local_forces(self):
-        self.sim.traverse_from(self.sim, accumulate=False)   # queued, not waited for
-
-    def add_remote(self, records):
-        cnt = int(records.shape[0])
-        records = records.to(self.gpu).contiguous()
-        if records.is_cuda:
-            torch.cuda.current_stream(self.gpu).synchronize()
-        if cnt > self._remote_cap:
-            if self.remote is not None:
-                self.remote.close()
-            self._remote_cap = max(int(cnt * 1.25) + 1024, self.n // 2)
-            p = self._nb.Params(**{**self.sim.params.__dict__, "num_points": self._remote_cap,
-                                   "max_num_codes_per_leaf": self.remote_codes_per_leaf,
-                                   "num_steps_validator": 0, "flags": 0})
-            self.remote = self._nb.Simulation(p)
-        if self.remote is None:
-            return
-        self.remote.set_sources_dev(records.data_ptr() if cnt else 0, cnt)
-        self.sim.traverse_from(self.remote, accumulate=True)
-
-    def finish_step(self):
-        self.sim.finish_step()
-
-    def work_weights(self):
-        """Per particle (current order): sources its group met in the own tree plus in the
-        imported tree.  Runs both traversals again to read their list lengths one after the
-        other; the accelerations come out as they were (same inputs, same sums)."""
-        import numpy as np
-        self.sim.traverse_from(self.sim, accumulate=False)
-        per_group = self.sim.get_list_len().astype(np.float64)
-        if self.remote is not None and self.remote.count() > 0:
-            self.sim.traverse_from(self.remote, accumulate=True)
-            per_group += self.sim.get_list_len()
-        n = self.sim.count()
-        return np.repeat(per_group, self.sim.params.traversal_group_size)[:n]
-
-    def get_particles(self):
-        return self.sim.get_state()
-
-    def set_particles(self, st):
-        if len(st["x"]) > self.sim.params.num_points:
-            raise RuntimeError(f"domain received {len(st['x'])} particles, handle capacity is "
-                               f"{self.sim.params.num_points}: create it with head-room")
-        self.sim.set_particles(st["x"], st["y"], st["z"], st["m"], st["vx"], st["vy"], st["vz"],
-                               st["ax"], st["ay"], st["az"], st["id"])
-        self.n = len(st["x"])
-        self.sim.set_traversal_range(0, 0)

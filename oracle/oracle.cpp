@@ -793,16 +793,17 @@ void orc_traverse_from(int nb, int group, const float *bx, const float *by, cons
                          gravity, domain, ax, ay, az, list_len, accumulate);
 }
 
-// Records (x,y,z,m) a remote domain with bounding box `box` (lo xyz, hi xyz) needs from this
-// tree: depth-first from the root; a node with children whose size^2 / d^2 < theta^2, d the
-// distance from the box to the node's centre of mass, contributes (com, mass); a node
+// Records (x,y,z,m) a remote domain whose particles lie in the union of `nboxes` boxes (lo xyz,
+// hi xyz each) needs from this tree: depth-first from the root; a node with children whose
+// size^2 / d^2 < theta^2, d the smallest distance from any of the boxes to the node's centre
+// of mass, contributes (com, mass); a node
 // without children contributes its points; anything else is opened.  Returns the number of
 // records; writes at most `cap` of them.
 int orc_let_export(const int32_t *first_child, const int32_t *num_children,
                    const int32_t *points_begin, const int32_t *points_end, const float *size,
                    const float *comx, const float *comy, const float *comz, const float *mass,
                    const float *x, const float *y, const float *z, const float *m,
-                   const float *box, float theta, float *out, int cap)
+                   const float *boxes, int nboxes, float theta, float *out, int cap)
 {
     int cnt = 0;
     auto emit = [&](float a, float b, float c, float d) {
@@ -817,10 +818,14 @@ int orc_let_export(const int32_t *first_child, const int32_t *num_children,
             for (int p = points_begin[o]; p <= points_end[o]; ++p) emit(x[p], y[p], z[p], m[p]);
             continue;
         }
-        const float dx = std::max(0.0f, std::max(box[0] - comx[o], comx[o] - box[3]));
-        const float dy = std::max(0.0f, std::max(box[1] - comy[o], comy[o] - box[4]));
-        const float dz = std::max(0.0f, std::max(box[2] - comz[o], comz[o] - box[5]));
-        const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        float d2 = 3.0e38f;
+        for (int b = 0; b < nboxes; ++b) {
+            const float *box = boxes + 6 * b;
+            const float dx = std::max(0.0f, std::max(box[0] - comx[o], comx[o] - box[3]));
+            const float dy = std::max(0.0f, std::max(box[1] - comy[o], comy[o] - box[4]));
+            const float dz = std::max(0.0f, std::max(box[2] - comz[o], comz[o] - box[5]));
+            d2 = std::min(d2, fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+        }
         if (size[o] * size[o] / d2 < theta * theta) emit(comx[o], comy[o], comz[o], mass[o]);
         else
             for (int c = first_child[o]; c < first_child[o] + num_children[o]; ++c) stack.push_back(c);

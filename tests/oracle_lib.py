@@ -155,16 +155,47 @@ def traverse_from(bodies, tree, comd, x, y, z, m, group, theta, eps, gravity, do
 
 
 def let_export(tree, comd, x, y, z, m, box, theta):
-    """(k, 4) float32 records a domain with bounding box `box` needs from this tree."""
+    """(k, 4) float32 records a domain needs from this tree; `box` = the (6,) bounding box of
+    the domain's particles or (b, 6) boxes whose union holds them (lo xyz, hi xyz each)."""
     x, y, z, m = _f32(x), _f32(y), _f32(z), _f32(m)
-    box = _f32(box)
+    box = _f32(box).reshape(-1, 6)
     targs, keep = _tree_args(tree, comd)
     cap = x.size + tree["n_oct"]
     out = np.empty((cap, 4), np.float32)
-    k = lib().orc_let_export(*targs, _p(x), _p(y), _p(z), _p(m), _p(box), C.c_float(theta), _p(out),
-                             C.c_int(cap))
+    k = lib().orc_let_export(*targs, _p(x), _p(y), _p(z), _p(m), _p(box), C.c_int(len(box)),
+                             C.c_float(theta), _p(out), C.c_int(cap))
     assert k <= cap
     return out[:k].copy()
+
+
+def frontier(tree, comd, xs, ys, zs, T):
+    """Top-of-tree records of nbody_let_frontier, restated in numpy: expand the breadth-first
+    prefix [0, K) of the octree, K the largest prefix that leaves at most T nodes; the frontier
+    is every child of an expanded node that is not itself expanded plus the leaves among the
+    expanded ones, ordered by first particle.  (T, 12) float32: lo xyz, hi xyz of the node's
+    particles, centre of mass xyz, mass, cell size, particle count; unused records lo = 3e38."""
+    nc, fc = tree["num_children"], tree["first_child"]
+    n_oct = tree["n_oct"]
+    L = min(n_oct, T)
+    inc = np.where(nc[:L] > 0, nc[:L] - 1, 0)
+    size = 1 + np.concatenate([[0], np.cumsum(inc)])        # frontier size after expanding [0, K)
+    K = int(np.nonzero(size <= T)[0].max())
+    expanded = [o for o in range(K) if nc[o] > 0]
+    C = max((int(fc[o] + nc[o]) for o in expanded), default=1)
+    nodes = [o for o in range(C) if o >= K or nc[o] == 0]
+    nodes.sort(key=lambda o: int(tree["points_begin"][o]))
+    assert len(nodes) <= T
+    rec = np.zeros((T, 12), np.float32)
+    rec[:, :3] = np.float32(3.0e38)
+    for j, o in enumerate(nodes):
+        pb, pe = int(tree["points_begin"][o]), int(tree["points_end"][o])
+        for k, a in enumerate((xs, ys, zs)):
+            rec[j, k] = a[pb:pe + 1].min()
+            rec[j, 3 + k] = a[pb:pe + 1].max()
+        rec[j, 6:10] = [comd["comx"][o], comd["comy"][o], comd["comz"][o], comd["mass"][o]]
+        rec[j, 10] = tree["size"][o]
+        rec[j, 11] = pe - pb + 1
+    return rec, nodes
 
 
 def direct_f64(x, y, z, m, eps, gravity, t0=0, t1=None):

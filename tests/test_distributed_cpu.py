@@ -161,10 +161,20 @@ class OracleLetBackend:
 
     def __init__(self, ic, idx, group, theta, dt, eps, bits):
         self.group, self.theta, self.dt, self.eps, self.bits = group, theta, dt, eps, bits
-        self.x, self.y, self.z, self.m = (ic[k][idx].copy() for k in ("x", "y", "z", "m"))
-        self.v = [ic[k][idx].copy() for k in ("vx", "vy", "vz")]
+        self.key_bits = 3 * bits
         self.gid = np.asarray(idx).copy()
-        self.acc = [np.zeros(len(idx), np.float32) for _ in range(3)]
+        self._install({k: ic[k][idx].copy() for k in ("x", "y", "z", "m", "vx", "vy", "vz")},
+                      [np.zeros(len(idx), np.float32) for _ in range(3)])
+
+    def _install(self, st, acc):
+        """Sort + build, as the library does after set_particles."""
+        b = O.full_build(st["x"], st["y"], st["z"], st["m"], 5.0, self.bits, 32)
+        p = b["perm"]
+        self.x, self.y, self.z, self.m = b["xs"], b["ys"], b["zs"], b["ms"]
+        self.v = [st[k][p] for k in ("vx", "vy", "vz")]
+        self.acc = [a[p] for a in acc]
+        self.gid = self.gid[p]
+        self.tree = b
 
     def update(self):
         x, y, z, vh = O.leapfrog_pos(self.dt, 5.0, self.x, self.y, self.z, *self.v, *self.acc)
@@ -183,23 +193,23 @@ class OracleLetBackend:
         self.acc = [ax, ay, az]
         self.work = ll.astype(np.float64)
 
-    def work_weights(self):
-        return np.repeat(self.work, self.group)[:len(self.x)]
-
-    def bbox(self):
-        return np.array([self.x.min(), self.y.min(), self.z.min(),
-                         self.x.max(), self.y.max(), self.z.max()], np.float32)
-
-    def let_export(self, boxes):
+    def frontier(self, T):
         b = self.tree
-        return [torch.from_numpy(O.let_export(b["tree"], b["com"], self.x, self.y, self.z, self.m,
-                                              box, self.theta)) for box in boxes]
+        rec, _ = O.frontier(b["tree"], b["com"], self.x, self.y, self.z, T)
+        return torch.from_numpy(rec)
+
+    def let_export(self, frontiers, me):
+        b = self.tree
+        fr = frontiers.numpy()
+        return [torch.empty(0, 4) if r == me else
+                torch.from_numpy(O.let_export(b["tree"], b["com"], self.x, self.y, self.z, self.m,
+                                              fr[r][:, :6], self.theta)) for r in range(len(fr))]
 
     def add_remote(self, records):
         r = records.numpy()
         if len(r) == 0:
             return
-        b = O.full_build(r[:, 0], r[:, 1], r[:, 2], r[:, 3], 5.0, self.bits, 32)
+        b = O.full_build(r[:, 0], r[:, 1], r[:, 2], r[:, 3], 5.0, self.bits, 8)
         ax, ay, az, ll = O.traverse_from((self.x, self.y, self.z), b["tree"], b["com"], b["xs"],
                                          b["ys"], b["zs"], b["ms"], self.group, self.theta,
                                          self.eps, 1.0, 5.0, acc=self.acc)
@@ -210,43 +220,46 @@ class OracleLetBackend:
         self.v = [(np.float32(0.5) * a * np.float32(self.dt) + h).astype(np.float32)
                   for a, h in zip(self.acc, self.vh)]
 
+    def key_lower_bounds(self, q):
+        return np.searchsorted(self.tree["codes_sorted"], np.asarray(q, np.uint64), side="left")
+
     def get_particles(self):
         return dict(x=self.x, y=self.y, z=self.z, m=self.m, vx=self.v[0], vy=self.v[1], vz=self.v[2],
                     ax=self.acc[0], ay=self.acc[1], az=self.acc[2], id=self.gid.astype(np.uint32))
 
     def set_particles(self, st):
-        self.x, self.y, self.z, self.m = st["x"], st["y"], st["z"], st["m"]
-        self.v = [st["vx"], st["vy"], st["vz"]]
-        self.acc = [st["ax"], st["ay"], st["az"]]
         self.gid = st["id"].astype(np.int64)
+        self._install(st, [st["ax"], st["ay"], st["az"]])
 
 
 def _let_worker(rank, world, port, n, q, rebalance_at=-1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ic = _ic(n)
-    idx = parallel.domain_slices(ic["x"], ic["y"], ic["z"], world)[rank]
+    idx = np.arange(n * rank // world, n * (rank + 1) // world)   # an arbitrary first ownership
     be = OracleLetBackend(ic, idx, 64, 0.5, 1e-3, 0.01, 21)
-    st = parallel.LetStepper(be)
+    st = parallel.LetStepper(be, records_per_domain=16)
+    moved = st.rebalance()                                        # -> Morton key ranges
+    keys0, split0 = be.tree["codes_sorted"].copy(), st.splitters.copy()
     sent = []
-    moved = 0
     for i in range(3):
         if i == rebalance_at:
-            moved = st.rebalance(sample=512, seed=i, weighted=True)
+            moved += st.rebalance()
         st.step()
         sent.append((st.last_sent, st.last_received))
     q.put((rank, be.gid, be.x, be.y, be.v[0], be.acc[0], be.acc[1], be.acc[2], sent, moved,
-           float(be.work_weights().sum())))
+           split0, keys0))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world,n,rebalance_at", [(2, 3000, -1), (3, 2500, -1), (3, 2500, 2)])
 def test_let_stepper_tracks_single_rank_and_direct_sum(world, n, rebalance_at):
-    """Domain decomposition over gloo ranks: every rank owns n/world particles and imports a
-    locally-essential tree from the others.  The forces are not bit-identical to a single
-    tree (different trees), so the check is accuracy against a float64 direct sum at the
-    final positions plus closeness of the trajectories to the single-rank run."""
+    """Domain decomposition over gloo ranks: every rank owns one Morton-key range (about
+    n/world particles) and imports a locally-essential tree from the others.  The forces are
+    not bit-identical to a single tree (different trees), so the check is accuracy against a
+    float64 direct sum at the final positions plus closeness of the trajectories to the
+    single-rank run."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -254,25 +267,24 @@ def test_let_stepper_tracks_single_rank_and_direct_sum(world, n, rebalance_at):
              for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=180) for _ in range(world)]
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     ic = _ic(n)
     x, y, vx, ax, ay, az = (np.full(n, np.nan, np.float32) for _ in range(6))
-    for rank, gid, rx, ry, rvx, rax, ray, raz, sent, moved, work in res:
+    for rank, gid, rx, ry, rvx, rax, ray, raz, sent, moved, split, keys0 in res:
         x[gid], y[gid], vx[gid], ax[gid], ay[gid], az[gid] = rx, ry, rvx, rax, ray, raz
         # a surface term: every step something is exchanged, far fewer records than particles
         assert all(0 < s < n and 0 < r < n for s, r in sent)
+        # ownership after the first re-balance = the rank's key range, about n / world particles
+        assert np.array_equal(split, res[0][10]) and int(split[0]) == 0 and int(split[-1]) == 1 << 63
+        assert np.all(keys0 >= split[rank]) and np.all(keys0 < split[rank + 1])
+        # both of a domain's cuts may miss their targets by the slack (or a 24-bit sub-bin)
+        assert abs(len(keys0) - n / world) <= 2 * 0.005 * n / world + 8
+        assert moved > 0
     assert not np.isnan(x).any()                      # every particle owned exactly once
     assert sum(len(r[1]) for r in res) == n
-    if rebalance_at >= 0:
-        # the disk has moved for two steps: the fresh bisection differs from the initial one
-        assert sum(r[9] for r in res) > 0
-        # the new cuts equalise work (body-source interactions of the last force evaluation),
-        # not particle counts
-        works = np.array([r[10] for r in res])
-        assert works.max() < 1.25 * works.mean(), works
     ref = OracleBackend(ic, n, 64, 0.5, 1e-3, 0.01, 21)
     for _ in range(3):
         ref.update()
@@ -295,55 +307,49 @@ def test_let_stepper_tracks_single_rank_and_direct_sum(world, n, rebalance_at):
     assert mean < 2e-3, mean
 
 
-def test_orb_cuts_follow_the_weights():
-    rng = np.random.default_rng(3)
-    pts = rng.uniform(0, 1, (20000, 3)) * np.array([4.0, 1.0, 1.0])      # longest axis: x
-    # unweighted: equal counts, as domain_slices cuts them
-    c = parallel.orb_cuts(pts, 4)
-    cnt = np.bincount(parallel.orb_assign(c, pts), minlength=4)
-    assert cnt.max() - cnt.min() <= 4
-    # the right half of the box costs nine times as much per particle
-    w = np.where(pts[:, 0] > 2.0, 9.0, 1.0)
-    c = parallel.orb_cuts(pts, 4, w)
-    dom = parallel.orb_assign(c, pts)
-    work = np.bincount(dom, weights=w, minlength=4)
-    assert work.max() < 1.02 * work.mean()
-    assert np.bincount(dom, minlength=4).max() > 2 * np.bincount(dom, minlength=4).min()
-    # three parts: 1/3 of the weight left of the first cut
-    c3 = parallel.orb_cuts(pts, 3, w)
-    work3 = np.bincount(parallel.orb_assign(c3, pts), weights=w, minlength=3)
-    assert work3.max() < 1.02 * work3.mean()
+def test_cuts_take_the_coarsest_edge_within_the_slack():
+    """nbody_dd_choose_edges / nbody_dd_refine_edge (host code of the library)."""
+    import nbody_amd as nb
+    # 16 bins, uniform: two parts -> the middle edge (8: three trailing zeros), exactly on target
+    edge, bin_ = nb.choose_edges(np.full(16, 100), 2, 0)
+    assert list(edge) == [8] and list(bin_) == [8]
+    # four parts -> edges 4, 8, 12
+    assert list(nb.choose_edges(np.full(16, 100), 4, 0)[0]) == [4, 8, 12]
+    # a target a hair beside a coarse edge: inside the slack the coarse edge wins over the nearer one
+    h = np.full(16, 100)
+    h[7] = 130                                        # cumulative at edge 8 = 830, target = 815
+    assert list(nb.choose_edges(h, 2, 20)[0]) == [8]
+    assert list(nb.choose_edges(h, 2, 10)[0]) == [-1]           # nothing within 10 of 815
+    assert list(nb.choose_edges(h, 2, 10)[1]) == [7]            # target inside bin 7 (700..830)
+    # refinement inside bin 7: 8 sub-bins of the 130 particles; target 815 = 700 + 115
+    sub = np.array([10, 20, 30, 10, 20, 20, 10, 10])            # cumulative 10 30 60 70 90 110 120 130
+    assert nb.refine_edge(sub, 700, 815, 0, 7 * 8, 7) == 6         # nearest (810 or 820): first wins ties
+    assert nb.refine_edge(sub, 700, 815, 30, 7 * 8, 7) == 8        # within 30: edges 5..8; edge 64 is the coarsest
+    assert nb.refine_edge(sub, 700, 815, 6, 7 * 8, 7) == 6         # within 6: 810 (edge 62) or 820 (edge 63): 62 is coarser
+    # all particles in one bin: every cut falls into it
+    h = np.zeros(4096, np.uint64)
+    h[1234] = 1000
+    edge, bin_ = nb.choose_edges(h, 4, 1)
+    assert list(edge) == [-1, -1, -1] and list(bin_) == [1234] * 3
 
 
-def test_cuts_snap_to_coarse_cell_boundaries():
-    """A bisection of a centred sphere puts its median a hair beside x = domain/2, the boundary
-    of the coarsest Morton cells; with `grid` the cut moves onto it, so that no domain holds
-    a thin slab of particles on the far side."""
-    S = (1 << 21) - 1
-    assert parallel.snap_to_cells(2.4999, 2.5002, (5.0, 21)) == (1 << 20) * 5.0 / S
-    assert parallel.snap_to_cells(1.0, 1.0000001, (5.0, 21)) is None          # no boundary inside
-    got = parallel.snap_to_cells(2.51, 2.52, (5.0, 21)) * S / 5.0
-    assert got == round(got) and int(round(got)) % (1 << 12) == 0            # the roundest in range
-    rng = np.random.default_rng(5)
+def test_morton_splitters_balance_a_clustered_set():
+    """The two-round histogram protocol on one 'rank' (the collectives are identities):
+    clustered keys, 5 domains, counts within the slack or one sub-bin of their targets."""
+    rng = np.random.default_rng(2)
     n = 200000
-    r = 0.5 * rng.uniform(0, 1, n) ** (1 / 3)
-    ct, ph = rng.uniform(-1, 1, n), rng.uniform(0, 2 * np.pi, n)
-    st = np.sqrt(1 - ct * ct)
-    x, y, z = 2.5 + r * st * np.cos(ph), 2.5 + r * st * np.sin(ph), 2.5 + r * ct
-    half = (1 << 20) * 5.0 / S
-    plain = parallel.domain_slices(x, y, z, 8)
-    snapped = parallel.domain_slices(x, y, z, 8, grid=(5.0, 21))
-    assert sorted(np.concatenate(snapped).tolist()) == list(range(n))       # still a partition
-    assert max(len(p) for p in snapped) < 1.02 * n / 8                      # within the slack
-    def straddlers(parts):
-        k = 0
-        for p in parts:
-            for a in (x, y, z):
-                lo, hi = (a[p] < half).sum(), (a[p] >= half).sum()
-                k += min(lo, hi)                                            # the minority side
-        return k
-    assert straddlers(plain) > 0 and straddlers(snapped) == 0
-    # the same rule in the re-balancing cuts
-    pts = np.stack([x, y, z], 1)
-    dom = parallel.orb_assign(parallel.orb_cuts(pts, 8, grid=(5.0, 21)), pts)
-    assert straddlers([np.nonzero(dom == d)[0] for d in range(8)]) == 0
+    pts = np.concatenate([rng.normal(2.5, 0.02, (n // 2, 3)), rng.uniform(0, 5, (n // 2, 3))]).clip(0, 5)
+    keys = np.sort(O.morton(pts[:, 0], pts[:, 1], pts[:, 2], 5.0, 21))
+    lb = lambda q: np.searchsorted(keys, np.asarray(q, np.uint64), side="left")
+    split, total = parallel.morton_splitters(lb, lambda a: a, 5, 63)
+    assert total == n and int(split[0]) == 0 and int(split[5]) == 1 << 63
+    cum = np.searchsorted(keys, split[1:5], side="left")           # particles before each cut
+    assert np.all(np.diff(split.astype(object)) >= 0)
+    assert np.abs(cum - n * np.arange(1, 5) / 5).max() <= max(0.005 * n / 5, 64), cum
+    # 30-bit keys and a uniform set: the cuts of 8 domains are the octant boundaries
+    g = (np.arange(40) + 0.5) * (5.0 / 40)                         # a lattice: equal octants
+    u = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    k30 = np.sort(O.morton(u[:, 0], u[:, 1], u[:, 2], 5.0, 10))
+    split, _ = parallel.morton_splitters(lambda q: np.searchsorted(k30, np.asarray(q, np.uint64)),
+                                         lambda a: a, 8, 30)
+    assert [int(v) for v in split] == [j << 27 for j in range(9)]
