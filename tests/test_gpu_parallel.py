@@ -46,6 +46,22 @@ def test_cpp_mirror_example_runs():
         assert abs(sim.get_state()["x"].mean() - float(m.group(3))) < 1e-8
 
 
+def test_cpp_rccl_example_single_rank():
+    """nbody_dd_* driven from C++ over RCCL (examples/dd_rccl_main.cpp) with one rank: the RCCL
+    vtable is bound and called; the tree equals the Python binding's for the same particles."""
+    exe = os.path.join(ROOT, "examples", "dd_rccl_main")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    n = 200000
+    out = subprocess.run([exe, "0", "1", "-", "sphere", str(n), "3"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    m = re.search(r"rank=0/1 particles=(\d+) octree_nodes=(\d+) records_sent=0 records_received=0", out.stdout)
+    assert m and int(m.group(1)) == n, out.stdout
+    with nb.Simulation(nb.Params(num_points=n, morton_bits=21, theta=0.6, dt=1e-6, softening_factor=0.1)) as sim:
+        sim.spawn_sphere()
+        sim.step(3)
+        assert sim.get_num_octree_nodes() == int(m.group(2))
+
+
 @pytest.fixture(scope="module")
 def single_rank_group():
     import torch.distributed as dist
