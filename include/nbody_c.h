@@ -57,6 +57,19 @@ enum {
                                           float arguments are widened and
                                           float results narrowed, the *_f64 entry points move
                                           doubles unchanged.                                     */
+    NBODY_FLAG_FIT_KEYS = 1u << 4,     /* Morton keys relative to a cube fitted to the particles
+                                          instead of [0, domain_size]^3 (the reference's,
+                                          src/cuda/points.cu:28-30).  With 10 bits per axis the
+                                          reference's cube leaves a system that fills a tenth of
+                                          the domain 100 cells across; the fitted cube gives it
+                                          all 1024.  The cube is kept from step to step while it
+                                          holds every particle and the particles' largest extent
+                                          is at least 0.4 of its side, and is otherwise re-drawn
+                                          around their bounding box (side = 1.25 x the largest
+                                          extent), on the device; octree cells subdivide it, so
+                                          node sizes are side / 2^level.  Float handles only, and
+                                          not for nbody_dd_* (the ranks need one common key
+                                          space).  nbody_get_key_domain() returns the cube.   */
     NBODY_FLAG_DEBUG_SMALL_STACK = 1u << 9, /* test aid: the traversal runs with a node stack of
                                             32 usable entries, so that its overflow handling
                                             (push-backs, depth-first rounds) is exercised;
@@ -195,6 +208,10 @@ typedef struct nbody_dev_view_f64 {
     void *stream;
 } nbody_dev_view_f64;
 int nbody_get_device_ptrs_f64(nbody_t *sim, nbody_dev_view_f64 *out);
+
+/* The cube the Morton keys of the last build were taken relative to: out[0..2] = lower
+ * corner, out[3] = side.  {0, 0, 0, domain_size} without NBODY_FLAG_FIT_KEYS. */
+int nbody_get_key_domain(nbody_t *sim, float *out);
 
 /* Sizes of the last built tree: U unique codes, M leaves, n_oct octree nodes. */
 int nbody_get_tree_counts(nbody_t *sim, int32_t *U, int32_t *M, int32_t *n_oct);

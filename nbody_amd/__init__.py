@@ -23,6 +23,7 @@ FLAG_TIMING = 1 << 0
 FLAG_NO_FUSED_VEL = 1 << 1
 FLAG_TIMING_STAGES = 1 << 2
 FLAG_FP64 = 1 << 3
+FLAG_FIT_KEYS = 1 << 4
 FLAG_DEBUG_WALK_ONLY = 1 << 8
 FLAG_DEBUG_SMALL_STACK = 1 << 9
 
@@ -111,7 +112,7 @@ EXPORTS = [
     "nbody_let_frontier", "nbody_let_frontier_dev", "nbody_let_export_dev", "nbody_sample_ic_range",
     "nbody_dd_create", "nbody_dd_destroy", "nbody_dd_last_error", "nbody_dd_spawn",
     "nbody_dd_rebalance", "nbody_dd_step", "nbody_dd_get_stats", "nbody_dd_choose_edges",
-    "nbody_dd_refine_edge",
+    "nbody_dd_refine_edge", "nbody_get_key_domain",
 ]
 
 _lib = None
@@ -207,6 +208,7 @@ def load_library() -> C.CDLL:
     lib.nbody_dd_refine_edge.argtypes = [C.POINTER(C.c_uint64), C.c_int32, C.c_uint64, C.c_uint64,
                                          C.c_uint64, C.c_uint64, C.c_int32]
     lib.nbody_dd_refine_edge.restype = C.c_int32
+    lib.nbody_get_key_domain.argtypes = [C.c_void_p, fp]
     _lib = lib
     return lib
 
@@ -424,6 +426,12 @@ class Simulation:
         fn, ptr = (self._lib.nbody_get_state_f64, _dptr) if f64 else (self._lib.nbody_get_state, _fptr)
         self._check(fn(self._h, *[ptr(out[k]) for k in names],
                        out["id"].ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
+
+    def key_domain(self) -> np.ndarray:
+        """(lo x, lo y, lo z, side) of the cube the Morton keys are taken relative to."""
+        out = np.empty(4, np.float32)
+        self._check(self._lib.nbody_get_key_domain(self._h, _fptr(out)))
         return out
 
     def tree_counts(self):

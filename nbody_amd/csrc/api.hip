@@ -54,9 +54,9 @@ void free_all(Sim *s)
     F(s->rt_level); F(s->rt_lb); F(s->rt_le); F(s->rt_left); F(s->rt_right); F(s->depth_key);
     F(s->bfs); F(s->octid); F(s->o_depth); F(s->o_first_child); F(s->o_num_children); F(s->o_lb);
     F(s->o_le); F(s->o_level); F(s->o_pb); F(s->o_pe); F(s->o_parent); F(s->o_size); F(s->o_wsum);
-    F(s->nodeA); F(s->nodeB); F(s->list_len); F(s->inter_dev); F(s->trav_tail); F(s->trav_heavy_ctrl); F(s->pot);
+    F(s->nodeA); F(s->nodeB); F(s->list_len); F(s->inter_dev); F(s->trav_tail); F(s->trav_ord); F(s->pot);
     F(s->tw_posm); F(s->tw_pot); F(s->ds_pot); F(s->let_boxes); F(s->let_counts);
-    F(s->red_scratch); F(s->red_out); F(s->let_mask); F(s->let_seg); F(s->let_frontier);
+    F(s->keybox); F(s->red_scratch); F(s->red_out); F(s->let_mask); F(s->let_seg); F(s->let_frontier);
     if (s->ev_ready) (void) hipEventDestroy(s->ev_ready);
     if (s->red_host) (void) hipHostFree(s->red_host);
     for (int k = 0; k < 3; ++k) { F(s->tw_v[k]); F(s->tw_vh[k]); F(s->tw_a[k]); F(s->ds_a[k]); }
@@ -168,20 +168,23 @@ int alloc_all(Sim *s)
             t.vhx[i] = s->vhx[i]; t.vhy[i] = s->vhy[i]; t.vhz[i] = s->vhz[i];
             t.vx[i] = s->vx[i]; t.vy[i] = s->vy[i]; t.vz[i] = s->vz[i];
         }
+        // launch-order lists: a group sits in exactly one (XCD, class) list, any of which may
+        // have to hold a whole XCD's share of the groups
         const size_t gcap = (n + 31) / 32;   // groups at the smaller group size
-        const size_t hw = 8 + TRAV_HEAVY_MAX + 3 * gcap;
-        NB_HIP(s, dalloc(&s->trav_heavy_ctrl, hw));
-        NB_HIP(s, hipMemsetAsync(s->trav_heavy_ctrl, 0, hw * sizeof(uint32_t), s->stream));
-        s->trav_heavy_list = s->trav_heavy_ctrl + 8;
-        s->trav_heavy_flag = s->trav_heavy_list + TRAV_HEAVY_MAX;
-        s->trav_cost[0] = s->trav_heavy_flag + gcap;
-        s->trav_cost[1] = s->trav_cost[0] + gcap;
-        t.cost[0] = s->trav_cost[0]; t.cost[1] = s->trav_cost[1];
-        t.heavy_ctrl = s->trav_heavy_ctrl;
-        t.heavy_list = s->trav_heavy_list;
-        t.heavy_flag = s->trav_heavy_flag;
+        t.ord_cap = (int32_t) (gcap / 8 + 8);
+        const size_t ctrl_words = (size_t) 2 * 2 * TRAV_ORD_CTRL;
+        const size_t list_words = (size_t) 2 * 2 * 8 * TRAV_CLASSES * t.ord_cap;
+        NB_HIP(s, dalloc(&s->trav_ord, ctrl_words + list_words));
+        NB_HIP(s, hipMemsetAsync(s->trav_ord, 0, ctrl_words * sizeof(uint32_t), s->stream));
+        t.ord_ctrl = s->trav_ord;
+        t.ord_list = s->trav_ord + ctrl_words;
         NB_HIP(s, dalloc(&s->trav_tail, 1));
         NB_HIP(s, hipMemcpy(s->trav_tail, &t, sizeof t, hipMemcpyHostToDevice));
+    }
+    if (s->p.flags & NBODY_FLAG_FIT_KEYS) {
+        const uint32_t init[12] = {0, 0, 0, 0, 0, 0x7f7fffffu, 0x7f7fffffu, 0x7f7fffffu, 0, 0, 0, 0};
+        NB_HIP(s, dalloc(&s->keybox, 12));
+        NB_HIP(s, hipMemcpy(s->keybox, init, sizeof init, hipMemcpyHostToDevice));
     }
     NB_HIP(s, dalloc(&s->let_boxes, (size_t) LET_REC * LET_MAX_BOXES));
     NB_HIP(s, dalloc(&s->let_counts, (size_t) LET_MAX_BOXES + 8));
@@ -370,6 +373,7 @@ int post_spawn(Sim *s)
     NB_HIP(s, s->fp64 ? launch64_export_view(s) : launch_export_view(s));
     s->spawned = true;
     s->pending_vel = false;
+    s->trav_ord_groups[0] = s->trav_ord_groups[1] = 0;
     s->ev_pending = 0;
     s->t_acc = nbody_timings{};
     s->hist_e.clear(); s->hist_e_ap.clear(); s->hist_err.clear();
@@ -596,6 +600,7 @@ int install_particles_dev(Sim *s, int n)
     NB_HIP(s, launch_export_view(s));
     s->spawned = true;
     s->pending_vel = false;
+    s->trav_ord_groups[0] = s->trav_ord_groups[1] = 0;
     s->ev_pending = 0;
     s->t_acc = nbody_timings{};
     return NBODY_OK;
@@ -769,6 +774,7 @@ int nbody_create(const nbody_params *params, nbody_t **out)
     if (p.max_num_codes_per_leaf < 1 || !(p.domain_size > 0.0f) || !(p.theta >= 0.0f) ||
         !(p.softening_factor > 0.0f))
         return NBODY_ERR_INVALID;
+    if ((p.flags & NBODY_FLAG_FIT_KEYS) && (p.flags & NBODY_FLAG_FP64)) return NBODY_ERR_INVALID;
     Sim *s = new (std::nothrow) Sim();
     if (!s) return NBODY_ERR_INVALID;
     s->p = p;
@@ -955,6 +961,18 @@ int nbody_get_num_octree_nodes(nbody_t *h, int32_t *out)
     int rc = fetch_counts(s);
     if (rc) return rc;
     *out = s->counts_host->n_oct;
+    return NBODY_OK;
+}
+
+int nbody_get_key_domain(nbody_t *h, float *out)
+{
+    NB_ENTER(h);
+    if (!out) return fail(s, NBODY_ERR_INVALID, "null output");
+    out[0] = out[1] = out[2] = 0.f;
+    out[3] = s->p.domain_size;
+    if (!s->keybox) return NBODY_OK;
+    NB_HIP(s, hipMemcpyAsync(out, s->keybox, 4 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    NB_HIP(s, hipStreamSynchronize(s->stream));
     return NBODY_OK;
 }
 

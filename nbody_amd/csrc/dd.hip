@@ -242,7 +242,7 @@ int nbody_dd_create(nbody_t *own, const nbody_comm *comm, nbody_dd_t **out)
         return NBODY_ERR_INVALID;
     *out = nullptr;
     Sim *s = reinterpret_cast<Sim *>(own);
-    if (s->fp64) return NBODY_ERR_STATE;
+    if (s->fp64 || s->keybox) return NBODY_ERR_STATE;   // one common key space: no fitted keys
     DD *d = new (std::nothrow) DD();
     if (!d) return NBODY_ERR_INVALID;
     d->own = s;

@@ -17,6 +17,14 @@ namespace nb {
 template <typename KeyT>
 __device__ __forceinline__ KeyT morton_code(float px, float py, float pz, float domain);
 
+// The cube the keys are taken relative to: [0, domain]^3 like the reference, or, with
+// NBODY_FLAG_FIT_KEYS, the cube (lo xyz, side) k_keyfit keeps in device memory.
+struct KeyCube { float ox, oy, oz, size; };
+__device__ __forceinline__ KeyCube key_cube(const float *__restrict__ keybox, float domain)
+{
+    return keybox ? KeyCube{keybox[0], keybox[1], keybox[2], keybox[3]} : KeyCube{0.f, 0.f, 0.f, domain};
+}
+
 template <>
 __device__ __forceinline__ uint32_t morton_code<uint32_t>(float px, float py, float pz,
                                                           float domain)
@@ -74,14 +82,130 @@ __global__ __launch_bounds__(256) void k_integrate_morton(
 }
 
 template <typename KeyT>
-__global__ __launch_bounds__(256) void k_morton(int n, float domain, const float *__restrict__ x,
+__global__ __launch_bounds__(256) void k_morton(int n, float domain, const float *__restrict__ keybox,
+                                                const float *__restrict__ x,
                                                 const float *__restrict__ y,
                                                 const float *__restrict__ z,
                                                 KeyT *__restrict__ codes)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    codes[i] = morton_code<KeyT>(x[i], y[i], z[i], domain);
+    const KeyCube c = key_cube(keybox, domain);
+    codes[i] = morton_code<KeyT>(x[i] - c.ox, y[i] - c.oy, z[i] - c.oz, c.size);
+}
+
+// ---------------------------------------------------------------------------
+// Fitted key domain (NBODY_FLAG_FIT_KEYS; not in the reference, whose keys always span
+// [0, domain_size]^3 -- with 10 bits per axis a system that fills a small part of the domain
+// is then a handful of cells across).  keybox = {lo x, lo y, lo z, side, valid} in device
+// memory, followed by six words of bounding-box scratch (min xyz, max xyz as bit patterns:
+// positions are >= 0, so float order is unsigned order).
+//   k_integrate_bbox : kick-drift without the encode, bounding box of the new positions
+//   k_bbox_soa       : bounding box of positions that are already there (spawn, set_state)
+//   k_keyfit         : one thread; keeps the cube while it holds every particle and the
+//                      particles' largest extent is at least 0.4 of its side, else re-draws it
+//                      around the box: side = 1.25 x the largest extent (at least
+//                      domain / 2^20), centred.  Float arithmetic in exactly this order (the
+//                      host checker does the same).  Resets the scratch.
+// then k_morton encodes relative to the cube.
+// ---------------------------------------------------------------------------
+// Workgroup reduction of per-thread bounds (bit patterns) and one guarded atomic per bound.
+__device__ __forceinline__ void block_bbox(uint32_t (&mn)[3], uint32_t (&mx)[3], uint32_t *box)
+{
+    __shared__ uint32_t s[6];
+    if (threadIdx.x < 6) s[threadIdx.x] = threadIdx.x < 3 ? 0x7f7fffffu : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        uint32_t a = mn[k], b = mx[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a = min(a, (uint32_t) __shfl_xor((int) a, o, 64));
+            b = max(b, (uint32_t) __shfl_xor((int) b, o, 64));
+        }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&s[k], a); atomicMax(&s[3 + k], b); }
+    }
+    __syncthreads();
+    // The global bounds only ever tighten: a workgroup that cannot improve one leaves it alone.
+    // Every access to these words, here and in k_keyfit, is an agent-scope atomic: they are
+    // updated from all XCDs, and an ordinary load may be served from an XCD's own L2.
+    if (threadIdx.x < 6) {
+        const uint32_t cur = __hip_atomic_load(&box[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x < 3) { if (s[threadIdx.x] < cur) atomicMin(&box[threadIdx.x], s[threadIdx.x]); }
+        else if (s[threadIdx.x] > cur) atomicMax(&box[threadIdx.x], s[threadIdx.x]);
+    }
+}
+
+constexpr int BBOX_GRID = 1024;   // workgroups of the two kernels below (grid-stride): 6 atomics each
+
+__global__ __launch_bounds__(256) void k_integrate_bbox(
+    int n, float dt, float domain, float *__restrict__ x, float *__restrict__ y,
+    float *__restrict__ z, const float *__restrict__ vx, const float *__restrict__ vy,
+    const float *__restrict__ vz, const float *__restrict__ ax, const float *__restrict__ ay,
+    const float *__restrict__ az, float *__restrict__ vhx, float *__restrict__ vhy,
+    float *__restrict__ vhz, uint32_t *box)
+{
+    uint32_t mn[3] = {0x7f7fffffu, 0x7f7fffffu, 0x7f7fffffu}, mx[3] = {0u, 0u, 0u};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        float hx = fmaf(0.5f * ax[i], dt, vx[i]);
+        float hy = fmaf(0.5f * ay[i], dt, vy[i]);
+        float hz = fmaf(0.5f * az[i], dt, vz[i]);
+        float px = fmaf(hx, dt, x[i]);
+        float py = fmaf(hy, dt, y[i]);
+        float pz = fmaf(hz, dt, z[i]);
+        reflect(px, hx, domain);
+        reflect(py, hy, domain);
+        reflect(pz, hz, domain);
+        x[i] = px; y[i] = py; z[i] = pz;
+        vhx[i] = hx; vhy[i] = hy; vhz[i] = hz;
+        const uint32_t v[3] = {__float_as_uint(px), __float_as_uint(py), __float_as_uint(pz)};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { mn[k] = min(mn[k], v[k]); mx[k] = max(mx[k], v[k]); }
+    }
+    block_bbox(mn, mx, box);
+}
+
+__global__ __launch_bounds__(256) void k_bbox_soa(int n, const float *__restrict__ x,
+                                                  const float *__restrict__ y,
+                                                  const float *__restrict__ z, uint32_t *box)
+{
+    uint32_t mn[3] = {0x7f7fffffu, 0x7f7fffffu, 0x7f7fffffu}, mx[3] = {0u, 0u, 0u};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t v[3] = {__float_as_uint(x[i]), __float_as_uint(y[i]), __float_as_uint(z[i])};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { mn[k] = min(mn[k], v[k]); mx[k] = max(mx[k], v[k]); }
+    }
+    block_bbox(mn, mx, box);
+}
+
+__global__ void k_keyfit(float *keybox, float domain)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t *box = reinterpret_cast<uint32_t *>(keybox + 5);
+    float lo[3], hi[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = __uint_as_float(__hip_atomic_load(&box[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        hi[a] = __uint_as_float(__hip_atomic_load(&box[3 + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        __hip_atomic_store(&box[a], 0x7f7fffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&box[3 + a], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const float ksize = keybox[3];
+    float side = 0.f;
+    bool inside = keybox[4] != 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        side = fmaxf(side, hi[a] - lo[a]);
+        inside = inside && lo[a] >= keybox[a] && hi[a] <= keybox[a] + ksize;
+    }
+    if (inside && side >= 0.4f * ksize) return;
+    float size_new = 1.25f * side;
+    const float floor_ = domain * (1.0f / 1048576.0f);
+    if (!(size_new >= floor_)) size_new = floor_;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) keybox[a] = 0.5f * (lo[a] + hi[a]) - 0.5f * size_new;
+    keybox[3] = size_new;
+    keybox[4] = 1.0f;
 }
 
 // Gather every per-particle array through the sort permutation in one pass and emit the
@@ -178,9 +302,29 @@ hipError_t launch_vel_kick_raw(int n, float dt, float keep, const float *vhx, co
                                const float *vhz, const float *ax, const float *ay, const float *az,
                                float *vx, float *vy, float *vz, hipStream_t st);
 
+static hipError_t launch_fit_and_encode(Sim *s)
+{
+    const int c = s->cur;
+    hipLaunchKernelGGL(k_keyfit, dim3(1), dim3(1), 0, s->stream, s->keybox, s->p.domain_size);
+    if (s->key_bytes == 4)
+        hipLaunchKernelGGL(k_morton<uint32_t>, dim3(nblk(s->n, 256)), dim3(256), 0, s->stream, s->n,
+                           s->p.domain_size, s->keybox, s->x[c], s->y[c], s->z[c], (uint32_t *) s->keys[0]);
+    else
+        hipLaunchKernelGGL(k_morton<uint64_t>, dim3(nblk(s->n, 256)), dim3(256), 0, s->stream, s->n,
+                           s->p.domain_size, s->keybox, s->x[c], s->y[c], s->z[c], (uint64_t *) s->keys[0]);
+    return hipGetLastError();
+}
+
 hipError_t launch_integrate_morton(Sim *s)
 {
     const int c = s->cur;
+    if (s->keybox) {   // fitted key domain: the cube is decided from the new positions
+        hipLaunchKernelGGL(k_integrate_bbox, dim3(std::min(nblk(s->n, 256), BBOX_GRID)), dim3(256), 0, s->stream, s->n,
+                           s->p.dt, s->p.domain_size, s->x[c], s->y[c], s->z[c], s->vx[c], s->vy[c],
+                           s->vz[c], s->ax, s->ay, s->az, s->vhx[c], s->vhy[c], s->vhz[c],
+                           reinterpret_cast<uint32_t *>(s->keybox + 5));
+        return launch_fit_and_encode(s);
+    }
     if (s->key_bytes == 4)
         hipLaunchKernelGGL(k_integrate_morton<uint32_t>, dim3(nblk(s->n, 256)), dim3(256), 0,
                            s->stream, s->n, s->p.dt, s->p.domain_size, s->x[c], s->y[c], s->z[c],
@@ -197,13 +341,18 @@ hipError_t launch_integrate_morton(Sim *s)
 hipError_t launch_morton_only(Sim *s)
 {
     const int c = s->cur;
+    if (s->keybox) {
+        hipLaunchKernelGGL(k_bbox_soa, dim3(std::min(nblk(s->n, 256), BBOX_GRID)), dim3(256), 0, s->stream, s->n, s->x[c],
+                           s->y[c], s->z[c], reinterpret_cast<uint32_t *>(s->keybox + 5));
+        return launch_fit_and_encode(s);
+    }
     if (s->key_bytes == 4)
         hipLaunchKernelGGL(k_morton<uint32_t>, dim3(nblk(s->n, 256)), dim3(256), 0, s->stream,
-                           s->n, s->p.domain_size, s->x[c], s->y[c], s->z[c],
+                           s->n, s->p.domain_size, (const float *) nullptr, s->x[c], s->y[c], s->z[c],
                            (uint32_t *) s->keys[0]);
     else
         hipLaunchKernelGGL(k_morton<uint64_t>, dim3(nblk(s->n, 256)), dim3(256), 0, s->stream,
-                           s->n, s->p.domain_size, s->x[c], s->y[c], s->z[c],
+                           s->n, s->p.domain_size, (const float *) nullptr, s->x[c], s->y[c], s->z[c],
                            (uint64_t *) s->keys[0]);
     return hipGetLastError();
 }

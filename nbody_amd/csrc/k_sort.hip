@@ -17,6 +17,12 @@
 #include "dev_utils.hpp"
 #include "nbody_internal.hpp"
 
+#ifndef NB_EXP_NORANK
+#define NB_EXP_NORANK 0   // experiment switches of scratch/sortbench.cpp: results are wrong with either
+#endif
+#ifndef NB_EXP_NOLB
+#define NB_EXP_NOLB 0
+#endif
 #ifndef NB_HIST_GRID
 #define NB_HIST_GRID 256
 #endif
@@ -108,12 +114,16 @@ __global__ __launch_bounds__(256) void k_sort_pass(
         const bool valid = li < tile_count;
         const uint32_t d = (uint32_t) (key[k] >> shift) & 255u;
         unsigned long long m = __ballot(valid);
+#if NB_EXP_NORANK
+        m = 1ull << lane;
+#else
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             const bool bit = (d >> b) & 1u;
             const unsigned long long bb = __ballot(bit);
             m &= bit ? bb : ~bb;
         }
+#endif
         const uint32_t r = (uint32_t) mbcnt(m);
         const uint32_t c = (uint32_t) __popcll(m);
         const uint32_t prev = s_whist[w][d];
@@ -134,7 +144,11 @@ __global__ __launch_bounds__(256) void k_sort_pass(
     uint32_t tot;
     const uint32_t dstart = block_excl_scan_u32<NW>(cnt, s_scan, &tot);
     const uint32_t gbase = block_excl_scan_u32<NW>(ghist[tid], s_scan, &tot);
+#if NB_EXP_NOLB
+    const uint32_t excl = 0; (void) status; (void) err;
+#else
     const uint32_t excl = lb_exclusive_thread(status, 256, tid, tile, cnt, err);
+#endif
     s_dstart[tid] = dstart;
     s_goff[tid] = gbase + excl - dstart;  // final position = s_goff[d] + position in tile
     __syncthreads();

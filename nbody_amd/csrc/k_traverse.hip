@@ -86,24 +86,42 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
     const v8f *__restrict__ posm2, const Float4 *__restrict__ nodeA,
     const NodeB *__restrict__ nodeB, float theta, float eps2, float gravity, float domain,
     float dt, float keep, const TravTail *__restrict__ tail, int cur, int accumulate,
-    int stack_limit, int kind, int sum_slot)
+    int stack_limit, int ord_rd, int ord_wr, int prev_groups)
 {
     __shared__ WaveLds lds[TRAV_WAVES];
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    // Launch order (see k_mark_heavy): the first TRAV_HEAVY_MAX wave slots take the groups
-    // marked heavy, one each; the other slots take all groups in Morton order, consecutive
-    // ones on the same XCD, and skip the marked ones.
+    // Launch order.  Groups differ in cost by a factor of several (a group whose 64
+    // Morton-consecutive bodies straddle a large cell boundary opens almost everything), and
+    // a kernel whose last-started waves are long ones ends with most of the chip idle.  Every
+    // wave therefore files its group, when done, under the XCD it ran on and one of
+    // TRAV_CLASSES cost classes (list length against the mean of the previous launch); the
+    // next launch against the same kind of tree hands the groups out per XCD, dearest class
+    // first, cheapest last -- the tail of the kernel is then made of short waves -- and in
+    // completion order (close to Morton order) within a class, so that neighbouring groups
+    // still share an XCD's L2.  ord_rd / ord_wr = index of the (kind, buffer) control block to
+    // read / write, -1 = plain Morton order / do not file.
     int g;
-    constexpr int HB = TRAV_HEAVY_MAX / TRAV_WAVES;
-    if ((int) blockIdx.x < HB) {
-        const int slot = (int) blockIdx.x * TRAV_WAVES + w;
-        if (slot >= (int) min(tail->heavy_ctrl[4 * kind + 1], (uint32_t) TRAV_HEAVY_MAX)) return;
-        g = g0 + (int) tail->heavy_list[slot];
+    const int xcd = (int) blockIdx.x & 7;
+    if (ord_rd >= 0) {
+        const uint32_t *cnt = tail->ord_ctrl + (size_t) ord_rd * TRAV_ORD_CTRL + xcd * TRAV_CLASSES;
+        int k = ((int) blockIdx.x >> 3) * TRAV_WAVES + w, c = 0;
+        // (words updated by atomics from every XCD are read with agent-scope atomic loads: an
+        // ordinary load may be served from a copy this XCD's L2 took before the updates; the
+        // eight counts are fetched by eight lanes in one round trip)
+        const int mine = lane < TRAV_CLASSES
+            ? (int) __hip_atomic_load(&cnt[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        for (; c < TRAV_CLASSES; ++c) {
+            const int nc = __builtin_amdgcn_readlane(mine, c);
+            if (k < nc) break;
+            k -= nc;
+        }
+        if (c == TRAV_CLASSES) return;   // beyond this XCD's share
+        g = g0 + (int) tail->ord_list[((size_t) (ord_rd * 8 + xcd) * TRAV_CLASSES + c) * tail->ord_cap + k];
     } else {
-        const int lblk = xcd_remap((int) blockIdx.x - HB, (int) gridDim.x - HB);
+        const int lblk = xcd_remap((int) blockIdx.x, (int) gridDim.x);
         g = g0 + lblk * TRAV_WAVES + w;
-        if (g >= g1 || tail->heavy_flag[g - g0]) return;
+        if (g >= g1) return;
     }
     WaveLds &L = lds[w];
     float *bxyf = reinterpret_cast<float *>(L.bxy);
@@ -554,9 +572,24 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
         }
     }
 #endif
-    if (lane == 0) {   // what the next launch against this kind of tree orders its groups by
-        tail->cost[kind][g] = total;
-        atomicAdd(&tail->heavy_ctrl[4 * kind + sum_slot], total >> 4);
+    if (ord_wr >= 0 && lane == 0) {   // file the group for the next launch against this kind of tree
+        uint32_t *ctrl = tail->ord_ctrl + (size_t) ord_wr * TRAV_ORD_CTRL;
+        atomicAdd(&ctrl[8 * TRAV_CLASSES], total >> 4);
+        // class by list length against the mean of the previous launch (16 * mean / 16 = ...)
+        int c = 3;
+        if (ord_rd >= 0 && prev_groups > 0) {
+            const uint32_t mean16 = __hip_atomic_load(&tail->ord_ctrl[(size_t) ord_rd * TRAV_ORD_CTRL + 8 * TRAV_CLASSES],
+                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (uint32_t) prev_groups;
+            const uint32_t t16 = total >> 4;   // both in units of 16 sources
+            c = t16 * 20u > mean16 * 40u ? 0 : t16 * 20u > mean16 * 30u ? 1 : t16 * 20u > mean16 * 25u ? 2
+              : t16 * 20u > mean16 * 20u ? 3 : t16 * 20u > mean16 * 17u ? 4 : t16 * 20u > mean16 * 14u ? 5
+              : t16 * 20u > mean16 * 11u ? 6 : 7;
+        }
+        const uint32_t slot = atomicAdd(&ctrl[xcd * TRAV_CLASSES + c], 1u);
+        if (slot < (uint32_t) tail->ord_cap)
+            tail->ord_list[((size_t) (ord_wr * 8 + xcd) * TRAV_CLASSES + c) * tail->ord_cap + slot] = (uint32_t) (g - g0);
+        else
+            atomicOr(tail->err, (uint32_t) DEV_ERR_RANGE);   // unreachable: a list holds an XCD's whole share
     }
     if (MODE == TRAV_POTENTIAL) {
         if (active) {
@@ -576,34 +609,6 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
             tail->vz[cur][b] = fmaf(0.5f * azv, dt, tail->vhz[cur][b]) * keep;
         }
     }
-}
-
-// ---------------------------------------------------------------------------
-// Heavy groups go first.  A group whose 64 Morton-consecutive bodies straddle a large cell
-// boundary is spread out in space, opens almost every node and has a source list several
-// times the mean; a domain of a decomposition whose cut plane lies just beside such a
-// boundary has a whole run of them at one end of its Morton order.  Started last, they
-// finish alone long after every other wave has gone (measured: +0.8 ms on a 4 ms kernel).
-// cost[i] = list length of group g0 + i in the previous launch against the same kind of
-// tree, sum16 = the sum of those lengths / 16 over that launch's prev_groups groups.  Groups
-// above twice the mean (at most TRAV_HEAVY_MAX of them) are listed and flagged; the traversal
-// starts the listed ones first and skips them in the Morton-ordered part of its grid.
-// heavy_n is zeroed by the launcher.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_mark_heavy(const uint32_t *__restrict__ cost, int ngroups,
-                                                    const uint32_t *__restrict__ sum16, int prev_groups,
-                                                    uint32_t *heavy_n, uint32_t *__restrict__ heavy_list,
-                                                    uint32_t *__restrict__ heavy_flag)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= ngroups) return;
-    const unsigned long long thr = prev_groups > 0 ? 32ull * *sum16 / (unsigned long long) prev_groups : ~0ull;
-    uint32_t flag = 0;
-    if (thr > 0 && (unsigned long long) cost[i] > thr) {
-        const uint32_t k = atomicAdd(heavy_n, 1u);
-        if (k < (uint32_t) TRAV_HEAVY_MAX) { heavy_list[k] = (uint32_t) i; flag = 1; }
-    }
-    heavy_flag[i] = flag;
 }
 
 // *out (u64, zeroed by the launcher) += sum over groups of list_len[g] * bodies_in_group(g).
@@ -720,26 +725,35 @@ static hipError_t traverse_impl(Sim *s, Sim *src, bool fuse_vel, int acc_flag, b
     const int g1 = s->trav_g1 < 0 ? ngroups : std::min(s->trav_g1, ngroups);
     const int c = s->cur;
     if (g1 > g0) {
-        const int grid = (g1 - g0 + TRAV_WAVES - 1) / TRAV_WAVES + TRAV_HEAVY_MAX / TRAV_WAVES;
-        // heavy_ctrl[4 * kind] = {sum A, heavy_n, sum B}: this launch reads the sum the previous
-        // launch of the same kind accumulated and accumulates into the other one
+        const int ng = g1 - g0;
+        // Launch order: a launch over all groups files every group under (XCD, cost class) for
+        // the next launch against the same kind of tree (own / another handle's), which then
+        // starts the dear groups first.  Partial ranges (sharded traversal) and the potential
+        // pass run in plain Morton order and leave the lists alone.
         const int kind = src == s ? 0 : 1;
-        const int rd = s->trav_sum_slot[kind], wr = 2 - rd;
-        uint32_t *ctrl = s->trav_heavy_ctrl + 4 * kind;
-        hipError_t me = hipMemsetAsync(ctrl + std::min(1, wr), 0, 2 * sizeof(uint32_t), s->stream);
-        if (me != hipSuccess) return me;
-        hipLaunchKernelGGL(k_mark_heavy, dim3((g1 - g0 + 255) / 256), dim3(256), 0, s->stream,
-                           s->trav_cost[kind] + g0, g1 - g0, ctrl + rd, s->trav_prev_groups[kind],
-                           ctrl + 1, s->trav_heavy_list, s->trav_heavy_flag);
-        s->trav_sum_slot[kind] = wr;
-        s->trav_prev_groups[kind] = g1 - g0;
+        const bool whole = g0 == 0 && g1 == ngroups && !potential;
+        int ord_rd = -1, ord_wr = -1;
+        if (whole) {
+            const int wr_buf = s->trav_ord_buf[kind] ^ 1;
+            if (s->trav_ord_groups[kind] == ng) ord_rd = kind * 2 + s->trav_ord_buf[kind];
+            ord_wr = kind * 2 + wr_buf;
+            hipError_t me = hipMemsetAsync(s->trav_ord + (size_t) ord_wr * TRAV_ORD_CTRL, 0,
+                                           TRAV_ORD_CTRL * sizeof(uint32_t), s->stream);
+            if (me != hipSuccess) return me;
+            s->trav_ord_buf[kind] = wr_buf;
+        }
+        const int prev_groups = s->trav_ord_groups[kind];
+        if (whole) s->trav_ord_groups[kind] = ng;
+        // blocks are dealt round-robin over the 8 XCDs; every XCD gets the same number
+        const int per_xcd = ((ng + TRAV_WAVES - 1) / TRAV_WAVES + 7) / 8;
+        const int grid = per_xcd * 8;
         const float eps2 = s->p.softening_factor * s->p.softening_factor;
         const float keep = 1.0f - s->p.velocity_dampening;
 #define NB_TRAV(GG, FV, WO)                                                                      \
     hipLaunchKernelGGL((k_traverse<GG, FV, (WO)>), dim3(grid), dim3(64 * TRAV_WAVES), 0, s->stream,    \
                        s->n, g0, g1, s->posm, src->posm, (const v8f *) src->posm2, src->nodeA,       \
                        src->nodeB, s->p.theta, eps2, s->p.gravity, s->p.domain_size, s->p.dt, keep,  \
-                       s->trav_tail, c, acc_flag, stack_limit, kind, wr)
+                       s->trav_tail, c, acc_flag, stack_limit, ord_rd, ord_wr, prev_groups)
         const bool walk_only = (s->p.flags & NBODY_FLAG_DEBUG_WALK_ONLY) != 0;
         // test aid: a node stack with 32 usable entries makes unexpanded push-backs and
         // depth-first single-node rounds the common case

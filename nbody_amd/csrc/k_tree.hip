@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void k_depth(const Counts *counts,
 // left-most / right-most chains through edge_delta = 0 nodes.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_emit(
-    Counts *counts, float domain, const uint32_t *__restrict__ dhist,
+    Counts *counts, float domain, const float *__restrict__ keybox, const uint32_t *__restrict__ dhist,
     const uint32_t *__restrict__ bfs, const uint32_t *__restrict__ octid,
     const int32_t *__restrict__ rt_pd, const int32_t *__restrict__ rt_level,
     const int32_t *__restrict__ rt_lb, const int32_t *__restrict__ rt_le,
@@ -356,6 +356,7 @@ __global__ __launch_bounds__(256) void k_emit(
     const int n_oct = n_bt - (int) dhist[255];
     const int root = n_bt == 1 ? 0 : 1;
     if (blockIdx.x == 0 && threadIdx.x == 0) counts->n_oct = n_oct;
+    if (keybox) domain = keybox[3];   // cells subdivide the cube the keys were taken relative to
     for (int o = blockIdx.x * 256 + threadIdx.x; o < n_oct; o += gridDim.x * 256) {
         const int r = (int) bfs[o];
         const bool leaf = (r & 1) == 0;
@@ -510,7 +511,7 @@ static hipError_t build_impl(Sim *s)
     launch_rank_pass(s->depth_key, s->o_depth, s->bfs, s->octid, &s->counts->n_bt, 2 * n,
                      s->dhist, s->rank_status, s->tickets + 2, &s->counts->err, st);
     hipLaunchKernelGGL(k_emit, dim3(node_grid), dim3(256), 0, st, s->counts, s->p.domain_size,
-                       s->dhist, s->bfs, s->octid, s->rt_pd, s->rt_level, s->rt_lb, s->rt_le,
+                       (const float *) s->keybox, s->dhist, s->bfs, s->octid, s->rt_pd, s->rt_level, s->rt_lb, s->rt_le,
                        s->rt_left, s->rt_right, s->lfc, s->first_pt, s->o_first_child,
                        s->o_num_children, s->o_lb, s->o_le, s->o_level, s->o_size, s->o_pb,
                        s->o_pe, s->o_parent, s->nodeB);

@@ -23,10 +23,12 @@ constexpr int LET_MAX_BOXES = 256;
 constexpr int LET_MAX_T = 32;                       // frontier records a domain advertises
 constexpr int LET_REC = 12;                         // floats per frontier record
 constexpr int LET_MASK_DOMAINS = 32;                // remote domains per export launch (mask bits)
-constexpr int TRAV_WAVES = 4;                       // groups (waves) per traversal workgroup
+#ifndef NB_TRAV_WAVES
+#define NB_TRAV_WAVES 1
+#endif
+constexpr int TRAV_WAVES = NB_TRAV_WAVES;           // groups (waves) per traversal workgroup
 constexpr int TRAV_STACK = 512;                     // LDS inner-node stack entries per wave
 constexpr int TRAV_LEAF_STACK = 544;                // LDS leaf stack entries per wave
-constexpr int TRAV_HEAVY_MAX = 1024;                // groups the traversal can start ahead of the rest
 constexpr int TRAV_PEND = 96;                       // LDS queue of candidates awaiting the exact test
 constexpr int MAX_DEPTH_BINS = 256;                 // depth key space of the node ranking pass
 constexpr int TIMING_RING = 64;
@@ -53,12 +55,14 @@ struct TravTail {
     float *vhx[2], *vhy[2], *vhz[2];
     float *vx[2], *vy[2], *vz[2];
     float *pot;
-    // launch order of the traversal (k_mark_heavy)
-    uint32_t *cost[2];            // per group: list length in the last launch against the own / another tree
-    uint32_t *heavy_ctrl;         // [2][4]: per kind {sum A, heavy_n, sum B, -}
-    const uint32_t *heavy_list;   // [TRAV_HEAVY_MAX] groups (relative to the launch's first) to start first
-    const uint32_t *heavy_flag;   // [groups] 1 = listed
+    // Launch order of the traversal (see k_traverse): per kind of source tree (own / another
+    // handle's) and per buffer (read by this launch / written for the next one of that kind):
+    uint32_t *ord_ctrl;           // [2 kinds][2 buffers][TRAV_ORD_CTRL]: counts [8 XCDs][8 classes], then sum of list lengths / 16
+    uint32_t *ord_list;           // [2 kinds][2 buffers][8 XCDs][8 classes][ord_cap] groups
+    int32_t ord_cap;
 };
+constexpr int TRAV_CLASSES = 8;                     // cost classes the traversal orders its groups by
+constexpr int TRAV_ORD_CTRL = 8 * TRAV_CLASSES + 8;
 
 // Device-resident counters written by the build kernels (one int each).
 struct Counts {
@@ -113,6 +117,10 @@ struct Sim {
     float *posm2 = nullptr;       // same, pair-interleaved: (x0,x1,y0,y1,z0,z1,m0,m1) per pair
     int cur = 0;                  // which buffer of each pair is current
 
+    // fitted key domain (NBODY_FLAG_FIT_KEYS): lo xyz, side, valid + 6 words of bounding-box
+    // scratch, device memory; null = keys span [0, domain_size]^3 like the reference's
+    float *keybox = nullptr;
+
     // sort
     void *keys[2]{};              // KeyT[n] ping-pong
     uint32_t *vals[2]{};          // index ping-pong; after the sort vals[sorted_buf] = perm
@@ -157,9 +165,9 @@ struct Sim {
     NodeB *nodeB = nullptr;
     uint32_t *list_len = nullptr; // [ceil(n/group)]
     TravTail *trav_tail = nullptr;
-    uint32_t *trav_heavy_ctrl = nullptr, *trav_heavy_list = nullptr, *trav_heavy_flag = nullptr;
-    uint32_t *trav_cost[2]{};
-    int trav_sum_slot[2] = {0, 0}, trav_prev_groups[2] = {0, 0};
+    uint32_t *trav_ord = nullptr;    // control words + group lists of the launch order (TravTail)
+    int trav_ord_buf[2] = {0, 0};    // per kind: the buffer the last launch of that kind wrote
+    int trav_ord_groups[2] = {0, 0}; // per kind: groups that launch covered (0 = no order yet)
     float *pot = nullptr;            // per-body potential sums (allocated by the first energy call)
     // LET exchange scratch
     float *let_boxes = nullptr;      // [LET_MAX_BOXES][LET_REC] device copy of caller-given boxes

@@ -189,17 +189,21 @@ int orc_build_octree(const uint64_t *unique, int U, const int32_t *lfc, int M,
 // ---------------------------------------------------------------------------
 namespace {
 
+// Keys are taken relative to the cube [lo, lo + domain]^3: the reference's is [0, domain_size]^3
+// (lo = 0, and x - 0 is x), the fitted key domain of this build (key_fit below) a cube around
+// the particles.
 template <typename T>
 void morton_impl(const T *x, const T *y, const T *z, int n, float domain, int bits,
-                 uint64_t *codes)
+                 uint64_t *codes, const float *lo = nullptr)
 {
     const T scale = (T) ((1u << bits) - 1u);
     const T dom = (T) domain;
+    const T ox = lo ? (T) lo[0] : T(0), oy = lo ? (T) lo[1] : T(0), oz = lo ? (T) lo[2] : T(0);
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < n; ++i) {
-        volatile T fx = x[i] / dom;
-        volatile T fy = y[i] / dom;
-        volatile T fz = z[i] / dom;
+        volatile T fx = (x[i] - ox) / dom;
+        volatile T fy = (y[i] - oy) / dom;
+        volatile T fz = (z[i] - oz) / dom;
         key_t_ qx = (key_t_) (fx * scale);
         key_t_ qy = (key_t_) (fy * scale);
         key_t_ qz = (key_t_) (fz * scale);
@@ -361,6 +365,10 @@ struct OrcSimT {
     std::vector<T> size, comx, comy, comz, mass;
     std::vector<uint32_t> list_len;
     int U = 0, M = 0, n_oct = 0;
+    // fitted key domain (not in the reference): keys relative to the cube [klo, klo + ksize]^3
+    int fit = 0;
+    bool kvalid = false;
+    float klo[3] = {0.f, 0.f, 0.f}, ksize = 0.f;
     double ms_build = 0, ms_traverse = 0, ms_integrate = 0;
     uint64_t interactions = 0;
 };
@@ -371,12 +379,48 @@ double now_ms()
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
+// Fitted key domain.  Not in the reference, whose keys always span [0, domain_size]^3: with 10
+// bits per axis that leaves a system that fills a small part of the domain a handful of cells
+// across.  The cube is kept while it holds every particle and the particles' largest extent
+// is at least 0.4 of its side; otherwise it is re-drawn around the bounding box: side =
+// 1.25 x the largest extent (at least domain_size / 2^20), centred on the box.  Float
+// arithmetic in exactly this order (the library does the same on the device).
+template <typename T>
+void key_fit(OrcSimT<T> *s)
+{
+    float lo[3], hi[3];
+    const T *p[3] = {s->x.data(), s->y.data(), s->z.data()};
+    for (int a = 0; a < 3; ++a) {
+        T mn = p[a][0], mx = p[a][0];
+        for (int i = 1; i < s->n; ++i) { mn = std::min(mn, p[a][i]); mx = std::max(mx, p[a][i]); }
+        lo[a] = (float) mn; hi[a] = (float) mx;
+    }
+    float side = 0.f;
+    bool inside = s->kvalid;
+    for (int a = 0; a < 3; ++a) {
+        side = std::max(side, hi[a] - lo[a]);
+        inside = inside && lo[a] >= s->klo[a] && hi[a] <= s->klo[a] + s->ksize;
+    }
+    if (inside && side >= 0.4f * s->ksize) return;
+    float size_new = 1.25f * side;
+    const float floor_ = s->domain * (1.0f / 1048576.0f);
+    if (!(size_new >= floor_)) size_new = floor_;
+    for (int a = 0; a < 3; ++a) s->klo[a] = 0.5f * (lo[a] + hi[a]) - 0.5f * size_new;
+    s->ksize = size_new;
+    s->kvalid = true;
+}
+
 // update_points + update_octree (src/cuda/simulation.cu:75-102).
 template <typename T>
 void sim_build(OrcSimT<T> *s, bool permute_all)
 {
     const int n = s->n;
-    morton_impl<T>(s->x.data(), s->y.data(), s->z.data(), n, s->domain, s->bits, s->codes.data());
+    if (s->fit) {
+        key_fit(s);
+        morton_impl<T>(s->x.data(), s->y.data(), s->z.data(), n, s->ksize, s->bits, s->codes.data(), s->klo);
+    } else {
+        morton_impl<T>(s->x.data(), s->y.data(), s->z.data(), n, s->domain, s->bits, s->codes.data());
+    }
     orc_sort(s->codes.data(), n, s->sorted.data(), s->perm.data());
     std::vector<T> tf;
     std::vector<uint32_t> ti;
@@ -391,7 +435,7 @@ void sim_build(OrcSimT<T> *s, bool permute_all)
     s->U = orc_unique(s->sorted.data(), n, s->unique.data(), s->first_pt.data());
     s->M = orc_coarsen(s->unique.data(), s->U, s->bits, s->max_codes, s->lfc.data());
     s->n_oct = orc_build_octree(s->unique.data(), s->U, s->lfc.data(), s->M, s->first_pt.data(),
-                                s->bits, s->domain, s->first_child.data(),
+                                s->bits, s->fit ? s->ksize : s->domain, s->first_child.data(),
                                 s->num_children.data(), s->lb.data(), s->le.data(),
                                 s->depth.data(), s->level.data(), s->size_f.data(), s->pb.data(),
                                 s->pe.data());
@@ -405,9 +449,10 @@ void sim_build(OrcSimT<T> *s, bool permute_all)
 template <typename T>
 OrcSimT<T> *sim_create(int n, int bits, int max_codes, int group, float theta, float dt,
                        float gravity, float eps, float domain, float damp, const T *x, const T *y,
-                       const T *z, const T *vx, const T *vy, const T *vz, const T *m)
+                       const T *z, const T *vx, const T *vy, const T *vz, const T *m, int fit = 0)
 {
     OrcSimT<T> *s = new OrcSimT<T>();
+    s->fit = fit;
     s->n = n; s->bits = bits; s->max_codes = max_codes; s->group = group;
     s->theta = theta; s->dt = dt; s->gravity = gravity; s->eps = eps; s->domain = domain;
     s->damp = damp;
@@ -942,6 +987,38 @@ OrcSim *orc_sim_create(int n, int bits, int max_codes, int group, float theta, f
 {
     return sim_create<float>(n, bits, max_codes, group, theta, dt, gravity, eps, domain, damp, x, y,
                              z, vx, vy, vz, m);
+}
+// The same with the fitted key domain (key_fit above).
+OrcSim *orc_sim_create_fit(int n, int bits, int max_codes, int group, float theta, float dt,
+                           float gravity, float eps, float domain, float damp, const float *x,
+                           const float *y, const float *z, const float *vx, const float *vy,
+                           const float *vz, const float *m)
+{
+    return sim_create<float>(n, bits, max_codes, group, theta, dt, gravity, eps, domain, damp, x, y,
+                             z, vx, vy, vz, m, 1);
+}
+// klo xyz, ksize of the current key cube (zeros without the fitted key domain).
+void orc_sim_get_key_domain(OrcSim *s, float *out)
+{
+    out[0] = s->klo[0]; out[1] = s->klo[1]; out[2] = s->klo[2]; out[3] = s->ksize;
+}
+// Tree arrays of the last build (n_oct entries each; pointers may be null) and the sorted codes.
+void orc_sim_get_tree(OrcSim *s, uint64_t *sorted, int32_t *first_child, int32_t *num_children,
+                      int32_t *points_begin, int32_t *points_end, float *size, float *comx,
+                      float *comy, float *comz, float *mass, uint32_t *list_len)
+{
+    const size_t no = (size_t) s->n_oct;
+    if (sorted) std::memcpy(sorted, s->sorted.data(), sizeof(uint64_t) * s->n);
+    if (first_child) std::memcpy(first_child, s->first_child.data(), 4 * no);
+    if (num_children) std::memcpy(num_children, s->num_children.data(), 4 * no);
+    if (points_begin) std::memcpy(points_begin, s->pb.data(), 4 * no);
+    if (points_end) std::memcpy(points_end, s->pe.data(), 4 * no);
+    if (size) std::memcpy(size, s->size_f.data(), 4 * no);
+    if (comx) std::memcpy(comx, s->comx.data(), 4 * no);
+    if (comy) std::memcpy(comy, s->comy.data(), 4 * no);
+    if (comz) std::memcpy(comz, s->comz.data(), 4 * no);
+    if (mass) std::memcpy(mass, s->mass.data(), 4 * no);
+    if (list_len) std::memcpy(list_len, s->list_len.data(), 4 * s->list_len.size());
 }
 void orc_sim_destroy(OrcSim *s) { delete s; }
 void orc_sim_step(OrcSim *s) { sim_step(s); }

@@ -37,6 +37,7 @@ def lib() -> C.CDLL:
     L.orc_num_threads.restype = C.c_int
     L.orc_let_export.restype = C.c_int
     L.orc_sim_create_dp.restype = C.c_void_p
+    L.orc_sim_create_fit.restype = C.c_void_p
     _lib = L
     return L
 
@@ -261,10 +262,13 @@ class OracleSim:
     """Whole-step host simulation (Simulation<T>::update sequencing over the oracle stages)."""
 
     def __init__(self, x, y, z, m, vx=None, vy=None, vz=None, *, bits=10, max_codes=32, group=64,
-                 theta=0.75, dt=1e-4, gravity=1.0, eps=1e-3, domain=5.0, damp=0.0):
+                 theta=0.75, dt=1e-4, gravity=1.0, eps=1e-3, domain=5.0, damp=0.0, fit=False):
+        """fit: keys relative to a cube fitted to the particles (the library's FLAG_FIT_KEYS)."""
         self.n = len(x)
         arrs = [_f32(a) if a is not None else None for a in (x, y, z, vx, vy, vz, m)]
-        self._h = C.c_void_p(lib().orc_sim_create(
+        create = lib().orc_sim_create_fit if fit else lib().orc_sim_create
+        self._group = group
+        self._h = C.c_void_p(create(
             C.c_int(self.n), C.c_int(bits), C.c_int(max_codes), C.c_int(group), C.c_float(theta),
             C.c_float(dt), C.c_float(gravity), C.c_float(eps), C.c_float(domain), C.c_float(damp),
             *[_p(a) for a in arrs]))
@@ -288,6 +292,27 @@ class OracleSim:
         a, b, c = C.c_double(), C.c_double(), C.c_double()
         lib().orc_sim_get_timings(self._h, C.byref(a), C.byref(b), C.byref(c))
         return dict(ms_integrate=a.value, ms_build=b.value, ms_traverse=c.value)
+
+    def key_domain(self):
+        out = np.zeros(4, np.float32)
+        lib().orc_sim_get_key_domain(self._h, _p(out))
+        return out
+
+    def tree(self):
+        """Sorted codes, octree arrays, centres of mass and list lengths of the last build/step."""
+        U, M, no, _ = self.counts()
+        out = dict(codes_sorted=np.empty(self.n, np.uint64))
+        for k in ("first_child", "num_children", "points_begin", "points_end"):
+            out[k] = np.empty(no, np.int32)
+        for k in ("size", "comx", "comy", "comz", "mass"):
+            out[k] = np.empty(no, np.float32)
+        out["list_len"] = np.empty((self.n + self._group - 1) // self._group, np.uint32)
+        lib().orc_sim_get_tree(self._h, _p(out["codes_sorted"]), _p(out["first_child"]),
+                               _p(out["num_children"]), _p(out["points_begin"]), _p(out["points_end"]),
+                               _p(out["size"]), _p(out["comx"]), _p(out["comy"]), _p(out["comz"]),
+                               _p(out["mass"]), _p(out["list_len"]))
+        out["n_oct"] = no
+        return out
 
     def close(self):
         if self._h:
