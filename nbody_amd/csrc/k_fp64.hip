@@ -13,6 +13,7 @@
 // kernels are plain one-body-per-lane code: sources staged through LDS and broadcast.
 #include <algorithm>
 
+#include "com_kernel.hpp"
 #include "dev_utils.hpp"
 #include "nbody_internal.hpp"
 
@@ -150,74 +151,6 @@ __global__ __launch_bounds__(256) void k64_twin_kick_drift(
     reflect_d(p.z, hz, domain);
     posm[i] = p;
     vhx[i] = hx; vhy[i] = hy; vhz[i] = hz;
-}
-
-// Centre of mass: the float kernel's single-launch climb (k_tree.hip, k_com) in double.
-// A thread sums its leaf's particles in index order and climbs; the last child to arrive
-// at a parent sums the parent's children in index order, so the summation order is fixed
-// and the host checker reproduces the result bit for bit
-// (src/cuda/octree.cu:109-217,292-346 is the level-by-level original).
-__device__ __forceinline__ void st_wt(double *p, double v)
-{
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double ld_wt(const double *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__global__ __launch_bounds__(256) void k64_com(const Counts *counts,
-                                               const int32_t *__restrict__ o_num_children,
-                                               const int32_t *__restrict__ o_first_child,
-                                               const int32_t *__restrict__ o_pb,
-                                               const int32_t *__restrict__ o_pe,
-                                               const int32_t *__restrict__ o_parent,
-                                               const Double4 *__restrict__ posm, Double4 *wsum,
-                                               Double4 *__restrict__ nodeA, uint32_t *counter,
-                                               uint32_t *err)
-{
-    const int n_oct = counts->n_oct;
-    for (int o = blockIdx.x * 256 + threadIdx.x; o < n_oct; o += gridDim.x * 256) {
-        if (o_num_children[o] != 0) continue;
-        double sx = 0.0, sy = 0.0, sz = 0.0, sm = 0.0;
-        const int pb = o_pb[o], pe = o_pe[o];
-        for (int p = pb; p <= pe; ++p) {
-            const Double4 q = posm[p];
-            sx = fma(q.w, q.x, sx);
-            sy = fma(q.w, q.y, sy);
-            sz = fma(q.w, q.z, sz);
-            sm += q.w;
-        }
-        int cur = o;
-        int guard = 0;
-        while (true) {
-            double *ws = reinterpret_cast<double *>(&wsum[cur]);
-            st_wt(ws + 0, sx); st_wt(ws + 1, sy); st_wt(ws + 2, sz); st_wt(ws + 3, sm);
-            nodeA[cur] = Double4{sx / sm, sy / sm, sz / sm, sm};
-            const int parent = o_parent[cur];
-            if (parent < 0) break;
-            if (++guard > 64) {   // deeper than any key allows: the parent chain is corrupt
-                atomicOr(err, (uint32_t) DEV_ERR_RANGE);
-                break;
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const uint32_t arrived = __hip_atomic_fetch_add(&counter[parent], 1u, __ATOMIC_RELAXED,
-                                                            __HIP_MEMORY_SCOPE_AGENT);
-            const int nc = o_num_children[parent];
-            if ((int) arrived != nc - 1) break;
-            __hip_atomic_store(&counter[parent], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int fc = o_first_child[parent];
-            sx = sy = sz = sm = 0.0;
-            for (int c = fc; c < fc + nc; ++c) {
-                const double *cs = reinterpret_cast<const double *>(&wsum[c]);
-                sx += ld_wt(cs + 0);
-                sy += ld_wt(cs + 1);
-                sz += ld_wt(cs + 2);
-                sm += ld_wt(cs + 3);
-            }
-            cur = parent;
-        }
-    }
 }
 
 // 1/sqrt(t), t > 0: v_rsq_f64 seeds one third-order step.  With e = 1 - t y^2,
@@ -551,9 +484,10 @@ hipError_t launch64_permute(Sim *s, bool all_fields)
 hipError_t launch64_com(Sim *s)
 {
     const int grid = std::min((2 * s->n + 255) / 256, 2048);
-    hipLaunchKernelGGL(k64_com, dim3(grid), dim3(256), 0, s->stream, s->counts, s->o_num_children,
+    hipLaunchKernelGGL((k_com_t<double, Double4>), dim3(grid), dim3(256), 0, s->stream, s->counts, s->o_num_children,
                        s->o_first_child, s->o_pb, s->o_pe, s->o_parent, s->d.posm, s->d.wsum,
-                       s->d.nodeA, s->com_counter, &s->counts->err);
+                       s->d.nodeA, s->com_counter, s->depth_key, s->tickets + COM_ROOTS_TICKET,
+                       &s->counts->err);
     return hipGetLastError();
 }
 

@@ -12,12 +12,9 @@
 //   leaf / per-depth / normalise COM kernels                      src/cuda/octree.cu:109-217,292-346
 // No count ever travels to the host during a build: kernels read U, M, n_bt, n_oct from
 // device memory and run grid-stride or ticketed tiles under host-known upper bounds.
+#include "com_kernel.hpp"
 #include "dev_utils.hpp"
 #include "nbody_internal.hpp"
-
-#ifndef NB_COM_ACQ_REL
-#define NB_COM_ACQ_REL 0
-#endif
 
 namespace nb {
 
@@ -350,7 +347,8 @@ __global__ __launch_bounds__(256) void k_emit(
     int32_t *__restrict__ o_first_child, int32_t *__restrict__ o_num_children,
     int32_t *__restrict__ o_lb, int32_t *__restrict__ o_le, int32_t *__restrict__ o_level,
     float *__restrict__ o_size, int32_t *__restrict__ o_pb, int32_t *__restrict__ o_pe,
-    int32_t *__restrict__ o_parent, NodeB *__restrict__ nodeB)
+    int32_t *__restrict__ o_parent, NodeB *__restrict__ nodeB, int com_local,
+    uint32_t *__restrict__ local_roots, uint32_t *n_local_roots)
 {
     const int n_bt = counts->n_bt;
     const int n_oct = n_bt - (int) dhist[255];
@@ -400,85 +398,17 @@ __global__ __launch_bounds__(256) void k_emit(
                 if ((bfs[fc + c] & 1u) == 0u) meta |= 1u << c;
         }
         nodeB[o] = leaf ? NodeB{size, pb, pe - pb + 1, meta} : NodeB{size, fc, nc, meta};
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Centre of mass, one launch.  A thread sums its leaf's particles (in index order), then
-// climbs: it bumps its parent's arrival counter and stops unless it was the last child to
-// arrive, in which case it sums the parent's children (in index order) and continues.
-// Summation order is therefore fixed whatever the arrival order, and the host oracle
-// reproduces it bit for bit.
-// Cross-workgroup hand-off of the children's sums: every sum is stored write-through
-// (agent-scope atomic stores), the storing wave drains its stores (s_waitcnt vmcnt(0))
-// before the agent-scope counter add, and the last arriver reads the sums with
-// agent-scope atomic loads that bypass its L1 -- only after its add has returned.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void st_wt(float *p, float v)
-{
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float ld_wt(const float *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__global__ __launch_bounds__(256) void k_com(const Counts *counts,
-                                             const int32_t *__restrict__ o_num_children,
-                                             const int32_t *__restrict__ o_first_child,
-                                             const int32_t *__restrict__ o_pb,
-                                             const int32_t *__restrict__ o_pe,
-                                             const int32_t *__restrict__ o_parent,
-                                             const Float4 *__restrict__ posm, Float4 *wsum,
-                                             Float4 *__restrict__ nodeA, uint32_t *counter,
-                                             uint32_t *err)
-{
-    const int n_oct = counts->n_oct;
-    for (int o = blockIdx.x * 256 + threadIdx.x; o < n_oct; o += gridDim.x * 256) {
-        if (o_num_children[o] != 0) continue;
-        float sx = 0.f, sy = 0.f, sz = 0.f, sm = 0.f;
-        const int pb = o_pb[o], pe = o_pe[o];
-        for (int p = pb; p <= pe; ++p) {
-            const Float4 q = posm[p];
-            sx = fmaf(q.w, q.x, sx);
-            sy = fmaf(q.w, q.y, sy);
-            sz = fmaf(q.w, q.z, sz);
-            sm += q.w;
-        }
-        int cur = o;
-        int guard = 0;
-        while (true) {
-            float *ws = reinterpret_cast<float *>(&wsum[cur]);
-            st_wt(ws + 0, sx); st_wt(ws + 1, sy); st_wt(ws + 2, sz); st_wt(ws + 3, sm);
-            nodeA[cur] = Float4{sx / sm, sy / sm, sz / sm, sm};
-            const int parent = o_parent[cur];
-            if (parent < 0) break;
-            if (++guard > 64) {   // deeper than any key allows: the parent chain is corrupt
-                atomicOr(err, (uint32_t) DEV_ERR_RANGE);
-                break;
+        // the centre-of-mass pass gives one wave to every inner node with at most com_local
+        // particles whose parent has more
+        if (!leaf && pe - pb + 1 <= com_local) {
+            bool big_parent = parent < 0;
+            if (!big_parent) {
+                int p = rt_pd[r] >> 1;
+                while (!(rt_pd[p] & 1)) p = rt_pd[p] >> 1;
+                const int plb = rt_lb[p >> 1], ple = rt_le[p >> 1];
+                big_parent = first_pt[lfc[ple + 1]] - first_pt[lfc[plb]] > com_local;
             }
-#if NB_COM_ACQ_REL
-            const uint32_t arrived = __hip_atomic_fetch_add(&counter[parent], 1u, __ATOMIC_ACQ_REL,
-                                                            __HIP_MEMORY_SCOPE_AGENT);
-#else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const uint32_t arrived = __hip_atomic_fetch_add(&counter[parent], 1u, __ATOMIC_RELAXED,
-                                                            __HIP_MEMORY_SCOPE_AGENT);
-#endif
-            const int nc = o_num_children[parent];
-            if ((int) arrived != nc - 1) break;
-            // every child has arrived: leave the counter at 0 for the next build
-            __hip_atomic_store(&counter[parent], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int fc = o_first_child[parent];
-            sx = sy = sz = sm = 0.f;
-            for (int c = fc; c < fc + nc; ++c) {
-                const float *cs = reinterpret_cast<const float *>(&wsum[c]);
-                sx += ld_wt(cs + 0);
-                sy += ld_wt(cs + 1);
-                sz += ld_wt(cs + 2);
-                sm += ld_wt(cs + 3);
-            }
-            cur = parent;
+            if (big_parent) local_roots[atomicAdd(n_local_roots, 1u)] = (uint32_t) o;
         }
     }
 }
@@ -514,7 +444,8 @@ static hipError_t build_impl(Sim *s)
                        (const float *) s->keybox, s->dhist, s->bfs, s->octid, s->rt_pd, s->rt_level, s->rt_lb, s->rt_le,
                        s->rt_left, s->rt_right, s->lfc, s->first_pt, s->o_first_child,
                        s->o_num_children, s->o_lb, s->o_le, s->o_level, s->o_size, s->o_pb,
-                       s->o_pe, s->o_parent, s->nodeB);
+                       s->o_pe, s->o_parent, s->nodeB, s->fp64 ? com_local<double>() : com_local<float>(),
+                       s->depth_key, s->tickets + COM_ROOTS_TICKET);
     return hipGetLastError();
 }
 
@@ -526,9 +457,10 @@ hipError_t launch_build(Sim *s)
 hipError_t launch_com(Sim *s)
 {
     const int grid = std::min((2 * s->n + 255) / 256, 2048);
-    hipLaunchKernelGGL(k_com, dim3(grid), dim3(256), 0, s->stream, s->counts, s->o_num_children,
+    hipLaunchKernelGGL((k_com_t<float, Float4>), dim3(grid), dim3(256), 0, s->stream, s->counts, s->o_num_children,
                        s->o_first_child, s->o_pb, s->o_pe, s->o_parent, s->posm, s->o_wsum,
-                       s->nodeA, s->com_counter, &s->counts->err);
+                       s->nodeA, s->com_counter, s->depth_key, s->tickets + COM_ROOTS_TICKET,
+                       &s->counts->err);
     return hipGetLastError();
 }
 
