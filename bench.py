@@ -40,7 +40,12 @@ THETA = 0.6
 EPS = 0.1
 DT = 1e-6
 FLOP_PER_INTERACTION = 20          # GPU-Gems/Nyland convention for one softened pair force
-BUILD_BYTES_PER_PARTICLE = 300     # algorithmic bytes of integrate+sort+permute+build+COM
+# algorithmic bytes per particle of integrate+sort+permute+build+COM, by key width: kick-drift
+# and encode 36 R + 28/32 W; all digit histograms in one key read 4/8; 4/8 digit passes of
+# 16/24 (key + index, read and written once); permute 36 R + 64 W; unique 12/20; tree kernels
+# (leaves, radix, depth, rank, emit) ~16; centre of mass 20
+BUILD_BYTES_PER_PARTICLE = {10: 64 + 4 + 4 * 16 + 100 + 12 + 16 + 20,    # 30-bit keys: 280
+                            21: 68 + 8 + 8 * 24 + 100 + 20 + 16 + 20}    # 63-bit keys: 424
 PEAK_FP32_TFLOPS = 157.3           # MI355X FP32 vector peak
 PEAK_FP64_TFLOPS = 78.6            # MI355X FP64 vector peak
 PEAK_HBM_GBS = 8000.0              # MI355X HBM3E peak
@@ -71,9 +76,66 @@ def cpu_baseline(ic, bits, steps=1, eps=EPS):
     mean = sum(ms) / len(ms)
     return {"value": round(mean, 1), "unit": "ms/step", "cores": cores, "kind": "port",
             "sample": f"{steps} step(s) of the full {len(ic['x'])}-particle workload after the "
-                      f"spawn build ({spawn_s:.1f} s); OpenMP traversal/integrate, serial sort+tree",
+                      f"spawn build ({spawn_s:.1f} s); every stage OpenMP (parallel stable sort, tree loops, level-parallel centre of mass, traversal)",
             "build_ms": round(tb / steps, 1), "traversal_ms": round(tt / steps, 1),
             "interactions_per_s": round(inter / (tt / steps / 1e3)) if tt > 0 else None}
+
+
+def direct_sum_block(no_cpu):
+    """BASELINE.json configs[2] on one GPU, reported beside the headline value: the O(N^2)
+    direct sum of 1,048,576 bodies (nbody_direct_sum_dev, the validator's kernel), timed with
+    events on torch's current stream, which is the stream the kernel is launched on."""
+    import numpy as np
+    import torch
+    import nbody_amd as nb
+    n, eps, grav = 1_048_576, 0.01, 1.0
+    ic = nb.sample_ic(nb.IC_SPHERE, n, 42)
+    posm = np.stack([ic["x"], ic["y"], ic["z"], np.full(n, 1.0 / n, np.float32)], 1).astype(np.float32)
+    dev_posm = torch.from_numpy(posm).cuda()
+    out = [torch.zeros(n, dtype=torch.float32, device="cuda") for _ in range(3)]
+    lib = nb.load_library()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def launch():
+        rc = lib.nbody_direct_sum_dev(dev_posm.data_ptr(), n, dev_posm.data_ptr(), n, eps, grav,
+                                      out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), 0, stream)
+        if rc != 0:
+            raise RuntimeError(f"nbody_direct_sum_dev failed with status {rc}")
+
+    launch()
+    torch.cuda.synchronize()
+    reps = 3
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    rate = float(n) * n / (ms * 1e-3)
+    tf = FLOP_PER_INTERACTION * rate / 1e12
+    cpu = None
+    if not no_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        nt = 65536
+        tc = time.perf_counter()
+        O.direct_f32(posm[:, 0], posm[:, 1], posm[:, 2], posm[:, 3], eps, grav, 0, nt)
+        tc = time.perf_counter() - tc
+        cpu = {"value": round(nt * float(n) / tc), "unit": "interactions/s",
+               "cores": O.lib().orc_num_threads(), "kind": "port",
+               "sample": f"{nt} target bodies x {n} sources ({tc:.1f} s), OpenMP over targets"}
+    return {"workload": "direct sum, 1,048,576-body uniform sphere r=0.5, m=1/N, eps=0.01 "
+                        "(the validator's all-pairs kernel, one launch)",
+            "ms_per_launch": round(ms, 3), "value": round(rate), "unit": "interactions/s",
+            "finite": bool(torch.isfinite(out[0]).all().item()),
+            "roofline": {"bound": "valu", "kernel": "k_direct", "achieved": round(tf, 2),
+                         "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_TFLOPS, 4),
+                         "traffic": None,
+                         "issue_bound_frac_at_sustained_clock": round(rate / (1024 * SUSTAINED_CLOCK_GHZ * 1e9 * 2), 4),
+                         "note": "20 FLOP x N^2 / mean kernel time over 3 launches; the ceiling of the "
+                                 "14-instruction pair is 2 interactions per cycle per SIMD"},
+            "cpu_baseline": cpu}
 
 
 def run_direct(args, world, rank, local_rank):
@@ -165,6 +227,8 @@ def main():
     ap.add_argument("--parallelism", choices=["let", "replicated"], default="let",
                     help="multi-GPU scheme (ignored with one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-direct-sum", action="store_true",
+                    help="1 GPU only: skip the direct-sum block reported beside the headline value")
     ap.add_argument("--evolve-steps", type=int, default=2000,
                     help="1 GPU only: after the timed region advance this many more steps (the cold "
                          "sphere collapses and rebounds within ~300) and time 20 steps of the "
@@ -384,12 +448,39 @@ def main():
                "interactions_per_step": round(t6["interactions"] / 10),
                "traversal_tflops": round(tf64, 2), "peak_fp64_vector_tflops": PEAK_FP64_TFLOPS,
                "frac": round(tf64 / PEAK_FP64_TFLOPS, 4)}
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
-            traffic = json.load(f)["k_traverse"]["bytes"]
-    except Exception:
-        pass
+    fit = None
+    if world == 1 and not args.no_alt_bits and not args.walk_only:
+        # 30-bit keys taken relative to a cube fitted to the particles (NBODY_FLAG_FIT_KEYS):
+        # the reference's key width at the resolution the particles need, for the record
+        p7 = nb.Params(**{**params.__dict__, "morton_bits": 10, "flags": nb.FLAG_TIMING | nb.FLAG_FIT_KEYS})
+        with nb.Simulation(p7) as s7:
+            s7.set_state(ic["x"], ic["y"], ic["z"], ic["m"])
+            s7.step(3)
+            s7.get_timings()
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            s7.step(20)
+            s7.sync()
+            tb = time.perf_counter()
+            t7 = s7.get_timings()
+            cube = s7.key_domain()
+        fit = {"morton_bits": 10, "fitted_key_domain": True, "cube_side": round(float(cube[3]), 5),
+               "ms_per_step": round((tb - ta) * 1e3 / 20, 4),
+               "traversal_ms": round(t7["ms_traverse"] / 20, 4),
+               "build_ms": round((t7["ms_integrate"] + t7["ms_sort"] + t7["ms_build"] + t7["ms_com"]) / 20, 4),
+               "interactions_per_step": round(t7["interactions"] / 20)}
+    direct = None
+    if world == 1 and not args.no_direct_sum and not args.walk_only:
+        direct = direct_sum_block(args.no_cpu_baseline)
+    traffic, traffic_src = None, None
+    for name in ("r2_traffic.json", "r1_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                traffic = json.load(f)["k_traverse"]["bytes"]
+            traffic_src = "profiles/" + name
+            break
+        except Exception:
+            pass
 
     if rank == 0:
         K = max(args.steps, 1)
@@ -398,7 +489,8 @@ def main():
         build_ms = (tim["ms_integrate"] + tim["ms_sort"] + tim["ms_build"] + tim["ms_com"]) / K
         inter_step_rank0 = tim["interactions"] / K
         tflops = FLOP_PER_INTERACTION * inter_step_rank0 / (trav_ms * 1e-3) / 1e12 if trav_ms else 0.0
-        build_gbs = BUILD_BYTES_PER_PARTICLE * n_here / (build_ms * 1e-3) / 1e9 if build_ms else 0.0
+        build_bytes = BUILD_BYTES_PER_PARTICLE[args.morton_bits]
+        build_gbs = build_bytes * n_here / (build_ms * 1e-3) / 1e9 if build_ms else 0.0
         out = {
             "metric": "ms/step (build+traversal) at 2M particles theta=0.6",
             "value": round(ms_step, 4),
@@ -435,11 +527,12 @@ def main():
             "finite": ok,
             "baseline_note": "vs_baseline = ms/step / 150 ms (reference README, RTX 500 Ada "
                              "laptop GPU; different hardware)",
-            "roofline": {"bound": "mfma", "kernel": "k_traverse", "achieved": round(tflops, 2),
+            "roofline": {"bound": "valu", "kernel": "k_traverse", "achieved": round(tflops, 2),
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(tflops / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
                          "traffic_note": "HBM-side bytes per launch from the committed rocprofv3 PMC "
-                                         "passes (profiles/r1_traffic.json), not measured in this run",
+                                         f"passes ({traffic_src}; steady-state dispatches only), not "
+                                         "measured in this run",
                          "pipe": "FP32 vector ALU (v_pk_fma_f32 / v_rsq_f32); priced against the dense "
                                  "f32 peak, which is the same 157.3 TFLOP/s for MFMA and packed VALU",
                          "note": "20 FLOP x exact interaction count / mean kernel time (HIP events on "
@@ -457,7 +550,12 @@ def main():
                                                  "s_memrealtime, profiles/r1_walk_profile.txt)"}},
             "roofline_build": {"bound": "hbm", "achieved": round(build_gbs, 1), "peak": PEAK_HBM_GBS,
                                "unit": "GB/s", "frac": round(build_gbs / PEAK_HBM_GBS, 4),
-                               "note": "300 algorithmic B/particle over integrate+sort+build+COM"},
+                               "bytes_per_particle": build_bytes,
+                               "note": f"{build_bytes} algorithmic B/particle over integrate+sort+permute+"
+                                       f"build+COM with the {3 * args.morton_bits}-bit keys this run used "
+                                       f"({BUILD_BYTES_PER_PARTICLE[10]} with 30-bit keys, "
+                                       f"{BUILD_BYTES_PER_PARTICLE[21]} with 63-bit keys); these kernels are "
+                                       "dependency-latency-bound at this size, not bandwidth-bound"},
         }
         if let:
             out["roofline"]["note"] += ("; rank 0's own-tree and imported-tree traversals "
@@ -472,6 +570,10 @@ def main():
             out["after_collapse"] = evolved
         if alt is not None:
             out["other_key_width"] = alt
+        if fit is not None:
+            out["fitted_30bit_keys"] = fit
+        if direct is not None:
+            out["direct_sum"] = direct
         if g32 is not None:
             out["other_group_size"] = g32
         if f64 is not None:

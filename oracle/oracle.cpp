@@ -36,6 +36,7 @@
 #include <cstring>
 #include <numeric>
 #include <vector>
+#include <parallel/algorithm>   // __gnu_parallel::stable_sort (libstdc++ parallel mode, OpenMP)
 
 #ifdef _OPENMP
 #include <omp.h>
@@ -159,6 +160,39 @@ inline T dist_sq(T ax, T ay, T az, T bx, T by, T bz)
     return std::fma(dz, dz, std::fma(dy, dy, dx * dx));
 }
 
+// out[] = the indices i in [0, n) with keep(i), ascending; returns how many.  Every thread
+// counts the kept indices of one contiguous chunk, the chunk offsets are summed serially,
+// then every thread writes its chunk: the same list as a serial sweep.
+template <typename Keep>
+static int compact_indices(int n, Keep keep, int32_t *out)
+{
+    int nthreads = 1;
+#ifdef _OPENMP
+    nthreads = omp_get_max_threads();
+#endif
+    std::vector<int> start(nthreads + 1, 0);
+#pragma omp parallel num_threads(nthreads)
+    {
+        int t = 0, nt = 1;
+#ifdef _OPENMP
+        t = omp_get_thread_num();
+        nt = omp_get_num_threads();
+#endif
+        const int lo = (int) ((int64_t) n * t / nt), hi = (int) ((int64_t) n * (t + 1) / nt);
+        int c = 0;
+        for (int i = lo; i < hi; ++i) c += keep(i) ? 1 : 0;
+        start[t + 1] = c;
+#pragma omp barrier
+#pragma omp single
+        for (int j = 0; j < nt; ++j) start[j + 1] += start[j];
+        int w = start[t];
+        for (int i = lo; i < hi; ++i)
+            if (keep(i)) out[w++] = i;
+        if (t == nt - 1) start[nthreads] = start[nt];
+    }
+    return start[nthreads];
+}
+
 template <typename T>
 static void permute(std::vector<T> &v, const std::vector<int32_t> &perm, std::vector<T> &tmp)
 {
@@ -217,23 +251,42 @@ void com_impl(int n_oct, const int32_t *first_child, const int32_t *num_children
               const T *z, const T *m, T *comx, T *comy, T *comz, T *mass)
 {
     std::vector<T> wx(n_oct), wy(n_oct), wz(n_oct);
-    for (int o = n_oct - 1; o >= 0; --o) {
-        T sx = 0, sy = 0, sz = 0, sm = 0;
-        if (num_children[o] == 0) {
-            for (int p = points_begin[o]; p <= points_end[o]; ++p) {
-                T mp = m[p];
-                sx = std::fma(mp, x[p], sx);
-                sy = std::fma(mp, y[p], sy);
-                sz = std::fma(mp, z[p], sz);
-                sm += mp;
-            }
-        } else {
-            for (int c = first_child[o]; c < first_child[o] + num_children[o]; ++c) {
-                sx += wx[c]; sy += wy[c]; sz += wz[c]; sm += mass[c];
-            }
-        }
-        wx[o] = sx; wy[o] = sy; wz[o] = sz; mass[o] = sm;
+    // Nodes are numbered depth-major and a node's children lie one depth further down, so the
+    // nodes of one depth are a contiguous range whose successor starts at the first child of
+    // its first inner node.  Depths are swept deepest first; the nodes of a depth are
+    // independent of each other, and every node's own sum keeps the order stated above.
+    std::vector<int> level_begin;
+    for (int lo = 0, hi = 1; lo < hi;) {
+        level_begin.push_back(lo);
+        int first = -1, last = -1;
+        for (int o = lo; o < hi; ++o)
+            if (num_children[o] != 0) { if (first < 0) first = o; last = o; }
+        if (first < 0) { level_begin.push_back(hi); break; }
+        lo = first_child[first];
+        hi = first_child[last] + num_children[last];
+        if (lo >= hi) { level_begin.push_back(lo); break; }
     }
+    for (int l = (int) level_begin.size() - 2; l >= 0; --l) {
+#pragma omp parallel for schedule(dynamic, 256)
+        for (int o = level_begin[l]; o < level_begin[l + 1]; ++o) {
+            T sx = 0, sy = 0, sz = 0, sm = 0;
+            if (num_children[o] == 0) {
+                for (int p = points_begin[o]; p <= points_end[o]; ++p) {
+                    T mp = m[p];
+                    sx = std::fma(mp, x[p], sx);
+                    sy = std::fma(mp, y[p], sy);
+                    sz = std::fma(mp, z[p], sz);
+                    sm += mp;
+                }
+            } else {
+                for (int c = first_child[o]; c < first_child[o] + num_children[o]; ++c) {
+                    sx += wx[c]; sy += wy[c]; sz += wz[c]; sm += mass[c];
+                }
+            }
+            wx[o] = sx; wy[o] = sy; wz[o] = sz; mass[o] = sm;
+        }
+    }
+#pragma omp parallel for schedule(static)
     for (int o = 0; o < n_oct; ++o) {
         comx[o] = wx[o] / mass[o];
         comy[o] = wy[o] / mass[o];
@@ -559,10 +612,13 @@ void orc_morton_dp(const double *x, const double *y, const double *z, int n, flo
 // ---------------------------------------------------------------------------
 void orc_sort(const uint64_t *codes, int n, uint64_t *sorted, int32_t *perm)
 {
+    // A stable sort has one possible result, so the multithreaded sort (sorted chunks merged
+    // pairwise, ties taken from the earlier chunk) gives the serial one's order.
     std::vector<int32_t> idx(n);
     std::iota(idx.begin(), idx.end(), 0);
-    std::stable_sort(idx.begin(), idx.end(),
-                     [&](int32_t a, int32_t b) { return codes[a] < codes[b]; });
+    __gnu_parallel::stable_sort(idx.begin(), idx.end(),
+                                [&](int32_t a, int32_t b) { return codes[a] < codes[b]; });
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < n; ++i) {
         perm[i] = idx[i];
         sorted[i] = codes[idx[i]];
@@ -576,14 +632,10 @@ void orc_sort(const uint64_t *codes, int n, uint64_t *sorted, int32_t *perm)
 // ---------------------------------------------------------------------------
 int orc_unique(const uint64_t *sorted, int n, uint64_t *unique, int32_t *first_pt)
 {
-    int u = 0;
-    for (int i = 0; i < n; ++i) {
-        if (i == 0 || sorted[i] != sorted[i - 1]) {
-            unique[u] = sorted[i];
-            first_pt[u] = i;
-            ++u;
-        }
-    }
+    const int u = compact_indices(n, [&](int i) { return i == 0 || sorted[i] != sorted[i - 1]; },
+                                  first_pt);
+#pragma omp parallel for schedule(static)
+    for (int j = 0; j < u; ++j) unique[j] = sorted[first_pt[j]];
     first_pt[u] = n;
     return u;
 }
@@ -603,6 +655,7 @@ int orc_coarsen(const uint64_t *unique, int U, int bits, int max_codes, int32_t 
         return 1;
     }
     std::vector<int> leaf_depth(U);
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < U; ++i)
         leaf_depth[i] = std::max(lcp(k, i, i - 1) / 3, lcp(k, i, i + 1) / 3) + 1;
 
@@ -620,9 +673,7 @@ int orc_coarsen(const uint64_t *unique, int U, int bits, int max_codes, int32_t 
         }
         flag[idx] = left_old == 0;
     }
-    int m = 0;
-    for (int i = 0; i < U; ++i)
-        if (flag[i]) lfc[m++] = i;
+    const int m = compact_indices(U, [&](int i) { return flag[i] != 0; }, lfc);
     lfc[m] = U;
     return m;
 }
@@ -652,6 +703,7 @@ int orc_build_octree(const uint64_t *unique, int U, const int32_t *lfc, int M,
     }
     // src/cuda/btree.cu:464-468: first code of each leaf.
     std::vector<key_t_> lk(M);
+#pragma omp parallel for schedule(static)
     for (int j = 0; j < M; ++j) lk[j] = unique[lfc[j]];
     Keys k{lk.data(), M, 3 * bits};
 
@@ -661,6 +713,9 @@ int orc_build_octree(const uint64_t *unique, int U, const int32_t *lfc, int M,
 
     // src/cuda/btree.cu:230-235: root.
     t.parent[1] = 0; t.depth[1] = 0; t.edge_delta[1] = 1;
+    // one iteration per internal node: it writes its own record and those of its two children,
+    // which no other node has as a child
+#pragma omp parallel for schedule(dynamic, 1024)
     for (int idx = 0; idx < M - 1; ++idx) {
         int d = sign(lcp(k, idx, idx + 1) - lcp(k, idx, idx - 1));
         int lcp_min = lcp(k, idx, idx - d);
@@ -689,6 +744,7 @@ int orc_build_octree(const uint64_t *unique, int U, const int32_t *lfc, int M,
         for (int n = 1; n < nbt; n <<= 1) rounds++;
         std::vector<int> p_in = t.parent, d_in = t.depth, p_out(nbt), d_out(nbt);
         for (int r = 0; r < rounds; ++r) {
+#pragma omp parallel for schedule(static)
             for (int i = 0; i < nbt; ++i) {
                 int cp = p_in[i], cd = d_in[i];
                 bool flag = cp && cd > 0;
@@ -704,11 +760,13 @@ int orc_build_octree(const uint64_t *unique, int U, const int32_t *lfc, int M,
     // src/cuda/btree.cu:497-559: stable sort by depth, permute, fix children.
     std::vector<int> order(nbt), inv(nbt);
     std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(),
-                     [&](int a, int b) { return t.depth[a] < t.depth[b]; });
+    __gnu_parallel::stable_sort(order.begin(), order.end(),
+                                [&](int a, int b) { return t.depth[a] < t.depth[b]; });
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < nbt; ++i) inv[order[i]] = i;
     Btree s;
     s.resize(nbt);
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < nbt; ++i) {
         int o = order[i];
         s.depth[i] = t.depth[o];
@@ -728,6 +786,7 @@ int orc_build_octree(const uint64_t *unique, int U, const int32_t *lfc, int M,
     const int n_oct = map[nbt - 1] + s.edge_delta[nbt - 1];
 
     // src/cuda/octree.cu:26-83 (build_octree) + :13-24 (traverse).
+#pragma omp parallel for schedule(static)
     for (int idx = 0; idx < nbt; ++idx) {
         if (!s.edge_delta[idx]) continue;
         int o = map[idx];
@@ -748,6 +807,7 @@ int orc_build_octree(const uint64_t *unique, int U, const int32_t *lfc, int M,
         num_children[o] = map[lbn] - map[fb] + 1;
     }
     // src/cuda/octree.cu:85-107.
+#pragma omp parallel for schedule(static)
     for (int o = 0; o < n_oct; ++o) {
         points_begin[o] = first_pt[lfc[leaves_begin[o]]];
         points_end[o] = first_pt[lfc[leaves_end[o] + 1]] - 1;
@@ -1090,6 +1150,17 @@ void orc_direct_dp(int n, int t0, int t1, const double *x, const double *y, cons
             pair_force<double>(x[i], y[i], z[i], x[j], y[j], z[j], m[j], fx, fy, fz, eps2);
         ax[i - t0] = gravity * fx; ay[i - t0] = gravity * fy; az[i - t0] = gravity * fz;
     }
+}
+
+// Threads the OpenMP regions of this file use from now on (tests compare a one-thread build
+// with a many-thread one).
+void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    omp_set_num_threads(n > 0 ? n : 1);
+#else
+    (void) n;
+#endif
 }
 
 int orc_num_threads(void)

@@ -520,3 +520,43 @@ def test_double_oracle_reproduces_committed_fixture():
     assert np.array_equal(ll, g["list_len"])
     # libm's sqrt and the divide are correctly rounded, fma is written out: same bits anywhere
     assert np.array_equal(ax, g["ax"]) and np.array_equal(ay, g["ay"]) and np.array_equal(az, g["az"])
+
+
+def test_multithreaded_build_equals_one_thread_build():
+    """The host build runs its sort, compactions, radix-tree loop, depth rounds, node ranking and
+    centre-of-mass sweep on every core when it is timed as the CPU baseline; every array it
+    produces, and the state after a step, must be the bits of a one-thread run."""
+    import ctypes as C
+    import nbody_amd as nb
+    L = O.lib()
+    L.orc_set_num_threads.argtypes = [C.c_int]
+    many = max(L.orc_num_threads(), 4)
+    n = 60000
+    ic = nb.sample_ic(nb.IC_DISK, n, 7)
+    # ties in the sort (10-bit keys on a thin disk) and a deep tree (63-bit keys)
+    for bits, max_codes in ((10, 4), (21, 32)):
+        out = []
+        for threads in (1, many):
+            L.orc_set_num_threads(threads)
+            try:
+                b = O.full_build(ic["x"], ic["y"], ic["z"], ic["m"], 5.0, bits, max_codes)
+                sim = O.OracleSim(ic["x"], ic["y"], ic["z"], ic["m"], ic["vx"], ic["vy"], ic["vz"], bits=bits,
+                                  max_codes=max_codes, group=32, theta=0.7, dt=1e-4, gravity=1.0, eps=0.01,
+                                  domain=5.0)
+                sim.step()
+                st = sim.state()
+                sim.close()
+            finally:
+                L.orc_set_num_threads(many)
+            out.append((b, st))
+        (b1, s1), (bm, sm) = out
+        for k in ("codes_sorted", "perm", "unique", "first_pt", "leaf_first_code_idx"):
+            assert np.array_equal(b1[k], bm[k]), (bits, k)
+        assert b1["tree"]["n_oct"] == bm["tree"]["n_oct"]
+        for k, v in b1["tree"].items():
+            if isinstance(v, np.ndarray):
+                assert np.array_equal(v, bm["tree"][k]), (bits, k)
+        for k in ("comx", "comy", "comz", "mass"):
+            assert np.array_equal(b1["com"][k], bm["com"][k]), (bits, k)
+        for k in ("x", "y", "z", "vx", "vy", "vz", "id"):
+            assert np.array_equal(s1[k], sm[k]), (bits, k)
