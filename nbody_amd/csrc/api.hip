@@ -116,14 +116,14 @@ int alloc_all(Sim *s)
     // sort scratch: ghist[8*256] | tickets[16] | status[P][tiles][256]
     s->sort_tiles = (int) ((n + SORT_TILE - 1) / SORT_TILE);
     const int passes = s->key_bytes == 4 ? 4 : 8;
-    s->sort_status_bytes = (8 * 256 + 16 + (size_t) passes * s->sort_tiles * 256) * sizeof(uint32_t);
+    s->sort_status_bytes = (8 * 256 + 16 + (size_t) passes * sort_status_rows(s->sort_tiles) * 256) * sizeof(uint32_t);
     NB_HIP(s, hipMalloc((void **) &s->ghist, s->sort_status_bytes));
 
     // build scratch zeroed once per build: tickets[16] | scan_status[2][T] | dhist[256] |
     // rank_status[R][256]
     s->max_scan_tiles = (int) ((n + 1023) / 1024);  // smallest compaction tile is 1024
     s->rank_tiles = (int) ((2 * n + SORT_TILE - 1) / SORT_TILE);
-    const size_t zwords = 16 + 2 * (size_t) s->max_scan_tiles + 256 + (size_t) s->rank_tiles * 256;
+    const size_t zwords = 16 + 2 * (size_t) s->max_scan_tiles + 256 + (size_t) sort_status_rows(s->rank_tiles) * 256;
     s->zero_bytes = (zwords * 4 + 15) / 16 * 16;
     NB_HIP(s, hipMalloc((void **) &s->zero_block, s->zero_bytes));
     uint32_t *zw = (uint32_t *) s->zero_block;

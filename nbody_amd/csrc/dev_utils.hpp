@@ -200,6 +200,74 @@ __device__ __forceinline__ uint32_t lb_exclusive_thread(uint32_t *status, int st
     return excl;
 }
 
+// Two-level look-back by a single thread (same role as lb_exclusive_thread).  Tiles form
+// groups of LB_GROUP consecutive tiles.  A tile publishes its aggregate, sums the aggregates
+// of the earlier tiles of its own group (they need nothing from anybody, so they are all
+// there after one round trip) and adds the exclusive prefix of its GROUP, which it finds by
+// the chained look-back over one word per group: the last tile of a group publishes the
+// group's total, looks back, and publishes the group's inclusive prefix.  When every tile of
+// a launch is resident at once (a few hundred tiles on 256 CUs) the one-level chain makes
+// tile t walk over nearly all of its t predecessors; here a tile reads at most LB_GROUP - 1
+// tile words and ntiles / LB_GROUP group words.
+// tile_status: one row of `stride` words per tile; group_status: one row per group.
+#ifndef NB_LB_GROUP
+#define NB_LB_GROUP 16
+#endif
+constexpr int LB_GROUP = NB_LB_GROUP;
+
+// Two calls, so that the caller can do work that needs no global offset between them while
+// the aggregates travel.
+__device__ __forceinline__ void lb2_publish(uint32_t *tile_status, int stride, int q, int tile,
+                                            uint32_t aggregate)
+{
+    lb_store(&tile_status[(size_t) tile * stride + q], LB_AGG | aggregate);
+}
+
+__device__ __forceinline__ uint32_t lb2_resolve(uint32_t *tile_status, uint32_t *group_status,
+                                                int stride, int q, int tile, uint32_t aggregate,
+                                                uint32_t *err)
+{
+    const int g = tile / LB_GROUP, j = tile % LB_GROUP;
+    uint32_t in_excl = 0;
+    {
+        uint32_t w[LB_GROUP - 1];
+        const uint32_t *row = tile_status + (size_t) g * LB_GROUP * stride + q;
+#pragma unroll
+        for (int i = 0; i < LB_GROUP - 1; ++i) w[i] = i < j ? lb_load(row + (size_t) i * stride) : LB_AGG;
+#pragma unroll
+        for (int i = 0; i < LB_GROUP - 1; ++i) {
+            uint32_t v = w[i];
+            if ((v >> 30) == 0u) v = lb_wait(row + (size_t) i * stride, err);
+            in_excl += v & LB_MASK;
+        }
+    }
+    const bool leader = j == LB_GROUP - 1;
+    const uint32_t group_total = in_excl + aggregate;   // meaningful for the leader only
+    uint32_t gex = 0;
+    if (g > 0) {
+        if (leader) lb_store(&group_status[(size_t) g * stride + q], LB_AGG | group_total);
+        int t = g - 1;
+        bool done = false;
+        while (!done && t >= 0) {
+            uint32_t w[LB_WINDOW];
+#pragma unroll
+            for (int i = 0; i < LB_WINDOW; ++i)
+                w[i] = (t - i >= 0) ? lb_load(&group_status[(size_t) (t - i) * stride + q]) : LB_PREFIX;
+#pragma unroll
+            for (int i = 0; i < LB_WINDOW; ++i) {
+                if (done) break;
+                uint32_t v = w[i];
+                if ((v >> 30) == 0u) v = lb_wait(&group_status[(size_t) (t - i) * stride + q], err);
+                gex += v & LB_MASK;
+                done = (v >> 30) == 2u;
+            }
+            t -= LB_WINDOW;
+        }
+    }
+    if (leader) lb_store(&group_status[(size_t) g * stride + q], LB_PREFIX | (gex + group_total));
+    return gex + in_excl;
+}
+
 // Bijective block-id remap that puts consecutive logical ids on the same XCD (blocks
 // are dealt round-robin over the 8 XCDs, each with a private L2).  Speed only.
 __device__ __forceinline__ int xcd_remap(int bid, int nblocks)

@@ -9,20 +9,14 @@
 //                 one global atomic per non-empty bin per workgroup).
 //   k_sort_pass : one launch per digit.  A workgroup takes a tile by atomic ticket, ranks
 //                 its keys with wave64 ballot matching, publishes the tile's 256 digit
-//                 counts and resolves their global offsets by chained look-back over the
-//                 earlier tiles (dev_utils.hpp), reorders the tile in LDS by digit and
-//                 writes each digit run to its final place with consecutive lanes on
+//                 counts, reorders the tile in LDS by digit, resolves the counts' global
+//                 offsets by the two-level look-back over the earlier tiles (dev_utils.hpp)
+//                 and writes each digit run to its final place with consecutive lanes on
 //                 consecutive addresses.  Keys and indices are read once and written
 //                 once per pass: 2*(sizeof(KeyT)+4) bytes per element per pass.
 #include "dev_utils.hpp"
 #include "nbody_internal.hpp"
 
-#ifndef NB_EXP_NORANK
-#define NB_EXP_NORANK 0   // experiment switches of scratch/sortbench.cpp: results are wrong with either
-#endif
-#ifndef NB_EXP_NOLB
-#define NB_EXP_NOLB 0
-#endif
 #ifndef NB_HIST_GRID
 #define NB_HIST_GRID 256
 #endif
@@ -73,7 +67,7 @@ __global__ __launch_bounds__(256) void k_sort_pass(
     const KeyT *__restrict__ kin, const uint32_t *__restrict__ vin, KeyT *__restrict__ kout,
     uint32_t *__restrict__ vout, uint32_t *__restrict__ inv_out, const int32_t *n_dev,
     int n_host, int shift, const uint32_t *__restrict__ ghist, uint32_t *status,
-    uint32_t *ticket, uint32_t *err)
+    uint32_t *group_status, uint32_t *ticket, uint32_t *err)
 {
     constexpr int NW = 4;
     constexpr int TILE = 256 * ITEMS;
@@ -114,16 +108,12 @@ __global__ __launch_bounds__(256) void k_sort_pass(
         const bool valid = li < tile_count;
         const uint32_t d = (uint32_t) (key[k] >> shift) & 255u;
         unsigned long long m = __ballot(valid);
-#if NB_EXP_NORANK
-        m = 1ull << lane;
-#else
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             const bool bit = (d >> b) & 1u;
             const unsigned long long bb = __ballot(bit);
             m &= bit ? bb : ~bb;
         }
-#endif
         const uint32_t r = (uint32_t) mbcnt(m);
         const uint32_t c = (uint32_t) __popcll(m);
         const uint32_t prev = s_whist[w][d];
@@ -141,16 +131,13 @@ __global__ __launch_bounds__(256) void k_sort_pass(
         s_whist[ww][tid] = cnt;
         cnt += c;
     }
+    // the tile's digit counts start their way to the other tiles now; the offsets they
+    // resolve to are needed only by the write-out, after the reorder in LDS
+    lb2_publish(status, 256, tid, tile, cnt);
     uint32_t tot;
     const uint32_t dstart = block_excl_scan_u32<NW>(cnt, s_scan, &tot);
     const uint32_t gbase = block_excl_scan_u32<NW>(ghist[tid], s_scan, &tot);
-#if NB_EXP_NOLB
-    const uint32_t excl = 0; (void) status; (void) err;
-#else
-    const uint32_t excl = lb_exclusive_thread(status, 256, tid, tile, cnt, err);
-#endif
     s_dstart[tid] = dstart;
-    s_goff[tid] = gbase + excl - dstart;  // final position = s_goff[d] + position in tile
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < ITEMS; ++k) {
@@ -162,6 +149,8 @@ __global__ __launch_bounds__(256) void k_sort_pass(
             s_vals[lp] = val[k];
         }
     }
+    const uint32_t excl = lb2_resolve(status, group_status, 256, tid, tile, cnt, err);
+    s_goff[tid] = gbase + excl - dstart;  // final position = s_goff[d] + position in tile
     __syncthreads();
     for (int j = tid; j < tile_count; j += 256) {
         const KeyT kk = s_keys[j];
@@ -179,10 +168,11 @@ void launch_rank_pass(const uint32_t *keys, uint32_t *keys_out, uint32_t *vals_o
                       uint32_t *inv_out, const int32_t *n_dev, int n_max, const uint32_t *hist,
                       uint32_t *status, uint32_t *ticket, uint32_t *err, hipStream_t st)
 {
+    // status: one row of 256 words per tile, then one per group of tiles
     const int grid = (n_max + SORT_TILE - 1) / SORT_TILE;
     hipLaunchKernelGGL((k_sort_pass<uint32_t, SORT_ITEMS, true>), dim3(grid), dim3(256), 0, st,
                        keys, (const uint32_t *) nullptr, keys_out, vals_out, inv_out, n_dev, 0, 0,
-                       hist, status, ticket, err);
+                       hist, status, status + (size_t) grid * 256, ticket, err);
 }
 
 template <typename KeyT, int NPASS>
@@ -190,10 +180,11 @@ static hipError_t sort_impl(Sim *s)
 {
     const int n = s->n;
     const int tiles = (n + SORT_TILE - 1) / SORT_TILE;   // <= s->sort_tiles (sized for cap)
-    const size_t zbytes = (8 * 256 + 16 + (size_t) NPASS * tiles * 256) * sizeof(uint32_t);
+    const int rows = sort_status_rows(tiles);            // tile rows + group rows of one pass
+    const size_t zbytes = (8 * 256 + 16 + (size_t) NPASS * rows * 256) * sizeof(uint32_t);
     hipError_t e = hipMemsetAsync(s->ghist, 0, zbytes, s->stream);
     if (e != hipSuccess) return e;
-    // layout of the zeroed block: ghist[8*256] | tickets[8] (+pad to 16) | status[P][tiles][256]
+    // layout of the zeroed block: ghist[8*256] | tickets[8] (+pad to 16) | status[P][rows][256]
     uint32_t *tickets = s->ghist + 8 * 256;
     uint32_t *status = tickets + 16;
     const int hgrid = std::min(std::max((n + 4095) / 4096, 1), NB_HIST_GRID);  // few blocks: the hot bins take one atomic per block
@@ -203,17 +194,18 @@ static hipError_t sort_impl(Sim *s)
     for (int p = 0; p < NPASS; ++p) {
         const KeyT *kin = (const KeyT *) s->keys[in];
         KeyT *kout = (KeyT *) s->keys[in ^ 1];
-        uint32_t *st = status + (size_t) p * tiles * 256;
+        uint32_t *st = status + (size_t) p * rows * 256;
+        uint32_t *gst = st + (size_t) tiles * 256;
         if (p == 0)
             hipLaunchKernelGGL((k_sort_pass<KeyT, SORT_ITEMS, true>), dim3(tiles), dim3(256), 0,
                                s->stream, kin, (const uint32_t *) nullptr, kout, s->vals[in ^ 1],
                                (uint32_t *) nullptr, (const int32_t *) nullptr, n, 8 * p,
-                               s->ghist + p * 256, st, tickets + p, &s->counts->err);
+                               s->ghist + p * 256, st, gst, tickets + p, &s->counts->err);
         else
             hipLaunchKernelGGL((k_sort_pass<KeyT, SORT_ITEMS, false>), dim3(tiles), dim3(256), 0,
                                s->stream, kin, (const uint32_t *) s->vals[in], kout,
                                s->vals[in ^ 1], (uint32_t *) nullptr, (const int32_t *) nullptr, n,
-                               8 * p, s->ghist + p * 256, st, tickets + p, &s->counts->err);
+                               8 * p, s->ghist + p * 256, st, gst, tickets + p, &s->counts->err);
         in ^= 1;
     }
     s->sorted_buf = in;  // NPASS is even: back in buffer 0

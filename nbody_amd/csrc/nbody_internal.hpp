@@ -16,6 +16,12 @@ constexpr int SORT_THREADS = 256;
 #endif
 constexpr int SORT_ITEMS = NB_SORT_ITEMS;           // keys per thread per radix tile
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;
+#ifndef NB_LB_GROUP
+#define NB_LB_GROUP 16
+#endif
+// rows of 256 look-back words one radix pass over `tiles` tiles needs: one per tile and one
+// per group of NB_LB_GROUP tiles (dev_utils.hpp, lb2_exclusive_thread)
+constexpr int sort_status_rows(int tiles) { return tiles + (tiles + NB_LB_GROUP - 1) / NB_LB_GROUP; }
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 16;                      // elements per thread in compaction tiles
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
@@ -126,7 +132,7 @@ struct Sim {
     uint32_t *vals[2]{};          // index ping-pong; after the sort vals[sorted_buf] = perm
     int sorted_buf = 0;
     uint32_t *ghist = nullptr;    // [8][256] digit histograms
-    uint32_t *sort_status = nullptr;  // [passes][tiles][256] look-back words + tickets
+    uint32_t *sort_status = nullptr;  // [passes][sort_status_rows(tiles)][256] look-back words + tickets
     size_t sort_status_bytes = 0;
     int sort_tiles = 0;
 
@@ -136,7 +142,7 @@ struct Sim {
     uint32_t *tickets = nullptr;      // [8]
     uint32_t *scan_status = nullptr;  // [3][max_scan_tiles]
     uint32_t *dhist = nullptr;        // [256] depth histogram
-    uint32_t *rank_status = nullptr;  // [rank_tiles][256]
+    uint32_t *rank_status = nullptr;  // [sort_status_rows(rank_tiles)][256]
     uint32_t *com_counter = nullptr;  // [2n] children-arrived counters
     int max_scan_tiles = 0, rank_tiles = 0;
 
