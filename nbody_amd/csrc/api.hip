@@ -54,7 +54,7 @@ void free_all(Sim *s)
     F(s->rt_level); F(s->rt_lb); F(s->rt_le); F(s->rt_left); F(s->rt_right); F(s->depth_key);
     F(s->bfs); F(s->octid); F(s->o_depth); F(s->o_first_child); F(s->o_num_children); F(s->o_lb);
     F(s->o_le); F(s->o_level); F(s->o_pb); F(s->o_pe); F(s->o_parent); F(s->o_size); F(s->o_wsum);
-    F(s->nodeA); F(s->nodeB); F(s->list_len); F(s->inter_dev); F(s->trav_tail); F(s->trav_ord); F(s->pot);
+    F(s->nodeA); F(s->nodeB); F(s->list_len); F(s->inter_dev); F(s->trav_tail); F(s->pot);
     F(s->tw_posm); F(s->tw_pot); F(s->ds_pot); F(s->let_boxes); F(s->let_counts);
     F(s->keybox); F(s->red_scratch); F(s->red_out); F(s->let_mask); F(s->let_seg); F(s->let_frontier);
     if (s->ev_ready) (void) hipEventDestroy(s->ev_ready);
@@ -168,16 +168,6 @@ int alloc_all(Sim *s)
             t.vhx[i] = s->vhx[i]; t.vhy[i] = s->vhy[i]; t.vhz[i] = s->vhz[i];
             t.vx[i] = s->vx[i]; t.vy[i] = s->vy[i]; t.vz[i] = s->vz[i];
         }
-        // launch-order lists: a group sits in exactly one (XCD, class) list, any of which may
-        // have to hold a whole XCD's share of the groups
-        const size_t gcap = (n + 31) / 32;   // groups at the smaller group size
-        t.ord_cap = (int32_t) (gcap / 8 + 8);
-        const size_t ctrl_words = (size_t) 2 * 2 * TRAV_ORD_CTRL;
-        const size_t list_words = (size_t) 2 * 2 * 8 * TRAV_CLASSES * t.ord_cap;
-        NB_HIP(s, dalloc(&s->trav_ord, ctrl_words + list_words));
-        NB_HIP(s, hipMemsetAsync(s->trav_ord, 0, ctrl_words * sizeof(uint32_t), s->stream));
-        t.ord_ctrl = s->trav_ord;
-        t.ord_list = s->trav_ord + ctrl_words;
         NB_HIP(s, dalloc(&s->trav_tail, 1));
         NB_HIP(s, hipMemcpy(s->trav_tail, &t, sizeof t, hipMemcpyHostToDevice));
     }
@@ -373,7 +363,6 @@ int post_spawn(Sim *s)
     NB_HIP(s, s->fp64 ? launch64_export_view(s) : launch_export_view(s));
     s->spawned = true;
     s->pending_vel = false;
-    s->trav_ord_groups[0] = s->trav_ord_groups[1] = 0;
     s->ev_pending = 0;
     s->t_acc = nbody_timings{};
     s->hist_e.clear(); s->hist_e_ap.clear(); s->hist_err.clear();
@@ -600,7 +589,6 @@ int install_particles_dev(Sim *s, int n)
     NB_HIP(s, launch_export_view(s));
     s->spawned = true;
     s->pending_vel = false;
-    s->trav_ord_groups[0] = s->trav_ord_groups[1] = 0;
     s->ev_pending = 0;
     s->t_acc = nbody_timings{};
     return NBODY_OK;

@@ -86,43 +86,18 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
     const v8f *__restrict__ posm2, const Float4 *__restrict__ nodeA,
     const NodeB *__restrict__ nodeB, float theta, float eps2, float gravity, float domain,
     float dt, float keep, const TravTail *__restrict__ tail, int cur, int accumulate,
-    int stack_limit, int ord_rd, int ord_wr, int prev_groups)
+    int stack_limit)
 {
     __shared__ WaveLds lds[TRAV_WAVES];
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    // Launch order.  Groups differ in cost by a factor of several (a group whose 64
-    // Morton-consecutive bodies straddle a large cell boundary opens almost everything), and
-    // a kernel whose last-started waves are long ones ends with most of the chip idle.  Every
-    // wave therefore files its group, when done, under the XCD it ran on and one of
-    // TRAV_CLASSES cost classes (list length against the mean of the previous launch); the
-    // next launch against the same kind of tree hands the groups out per XCD, dearest class
-    // first, cheapest last -- the tail of the kernel is then made of short waves -- and in
-    // completion order (close to Morton order) within a class, so that neighbouring groups
-    // still share an XCD's L2.  ord_rd / ord_wr = index of the (kind, buffer) control block to
-    // read / write, -1 = plain Morton order / do not file.
-    int g;
-    const int xcd = (int) blockIdx.x & 7;
-    if (ord_rd >= 0) {
-        const uint32_t *cnt = tail->ord_ctrl + (size_t) ord_rd * TRAV_ORD_CTRL + xcd * TRAV_CLASSES;
-        int k = ((int) blockIdx.x >> 3) * TRAV_WAVES + w, c = 0;
-        // (words updated by atomics from every XCD are read with agent-scope atomic loads: an
-        // ordinary load may be served from a copy this XCD's L2 took before the updates; the
-        // eight counts are fetched by eight lanes in one round trip)
-        const int mine = lane < TRAV_CLASSES
-            ? (int) __hip_atomic_load(&cnt[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-        for (; c < TRAV_CLASSES; ++c) {
-            const int nc = __builtin_amdgcn_readlane(mine, c);
-            if (k < nc) break;
-            k -= nc;
-        }
-        if (c == TRAV_CLASSES) return;   // beyond this XCD's share
-        g = g0 + (int) tail->ord_list[((size_t) (ord_rd * 8 + xcd) * TRAV_CLASSES + c) * tail->ord_cap + k];
-    } else {
-        const int lblk = xcd_remap((int) blockIdx.x, (int) gridDim.x);
-        g = g0 + lblk * TRAV_WAVES + w;
-        if (g >= g1) return;
-    }
+    // Groups are taken in Morton order, XCD-contiguous: workgroups are dealt round-robin over
+    // the 8 XCDs, so the remap gives every XCD one contiguous eighth of the groups, and groups
+    // that run at the same time on an XCD are neighbours in space and share their sources in
+    // its L2.
+    const int lblk = xcd_remap((int) blockIdx.x, (int) gridDim.x);
+    const int g = g0 + lblk * TRAV_WAVES + w;
+    if (g >= g1) return;
     WaveLds &L = lds[w];
     float *bxyf = reinterpret_cast<float *>(L.bxy);
     float *bzf = reinterpret_cast<float *>(L.bz);
@@ -572,25 +547,6 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
         }
     }
 #endif
-    if (ord_wr >= 0 && lane == 0) {   // file the group for the next launch against this kind of tree
-        uint32_t *ctrl = tail->ord_ctrl + (size_t) ord_wr * TRAV_ORD_CTRL;
-        atomicAdd(&ctrl[8 * TRAV_CLASSES], total >> 4);
-        // class by list length against the mean of the previous launch (16 * mean / 16 = ...)
-        int c = 3;
-        if (ord_rd >= 0 && prev_groups > 0) {
-            const uint32_t mean16 = __hip_atomic_load(&tail->ord_ctrl[(size_t) ord_rd * TRAV_ORD_CTRL + 8 * TRAV_CLASSES],
-                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (uint32_t) prev_groups;
-            const uint32_t t16 = total >> 4;   // both in units of 16 sources
-            c = t16 * 20u > mean16 * 40u ? 0 : t16 * 20u > mean16 * 30u ? 1 : t16 * 20u > mean16 * 25u ? 2
-              : t16 * 20u > mean16 * 20u ? 3 : t16 * 20u > mean16 * 17u ? 4 : t16 * 20u > mean16 * 14u ? 5
-              : t16 * 20u > mean16 * 11u ? 6 : 7;
-        }
-        const uint32_t slot = atomicAdd(&ctrl[xcd * TRAV_CLASSES + c], 1u);
-        if (slot < (uint32_t) tail->ord_cap)
-            tail->ord_list[((size_t) (ord_wr * 8 + xcd) * TRAV_CLASSES + c) * tail->ord_cap + slot] = (uint32_t) (g - g0);
-        else
-            atomicOr(tail->err, (uint32_t) DEV_ERR_RANGE);   // unreachable: a list holds an XCD's whole share
-    }
     if (MODE == TRAV_POTENTIAL) {
         if (active) {
             const float p = fx;   // the body's own term never entered the sum (pot_rsq)
@@ -726,24 +682,6 @@ static hipError_t traverse_impl(Sim *s, Sim *src, bool fuse_vel, int acc_flag, b
     const int c = s->cur;
     if (g1 > g0) {
         const int ng = g1 - g0;
-        // Launch order: a launch over all groups files every group under (XCD, cost class) for
-        // the next launch against the same kind of tree (own / another handle's), which then
-        // starts the dear groups first.  Partial ranges (sharded traversal) and the potential
-        // pass run in plain Morton order and leave the lists alone.
-        const int kind = src == s ? 0 : 1;
-        const bool whole = g0 == 0 && g1 == ngroups && !potential;
-        int ord_rd = -1, ord_wr = -1;
-        if (whole) {
-            const int wr_buf = s->trav_ord_buf[kind] ^ 1;
-            if (s->trav_ord_groups[kind] == ng) ord_rd = kind * 2 + s->trav_ord_buf[kind];
-            ord_wr = kind * 2 + wr_buf;
-            hipError_t me = hipMemsetAsync(s->trav_ord + (size_t) ord_wr * TRAV_ORD_CTRL, 0,
-                                           TRAV_ORD_CTRL * sizeof(uint32_t), s->stream);
-            if (me != hipSuccess) return me;
-            s->trav_ord_buf[kind] = wr_buf;
-        }
-        const int prev_groups = s->trav_ord_groups[kind];
-        if (whole) s->trav_ord_groups[kind] = ng;
         // blocks are dealt round-robin over the 8 XCDs; every XCD gets the same number
         const int per_xcd = ((ng + TRAV_WAVES - 1) / TRAV_WAVES + 7) / 8;
         const int grid = per_xcd * 8;
@@ -753,7 +691,7 @@ static hipError_t traverse_impl(Sim *s, Sim *src, bool fuse_vel, int acc_flag, b
     hipLaunchKernelGGL((k_traverse<GG, FV, (WO)>), dim3(grid), dim3(64 * TRAV_WAVES), 0, s->stream,    \
                        s->n, g0, g1, s->posm, src->posm, (const v8f *) src->posm2, src->nodeA,       \
                        src->nodeB, s->p.theta, eps2, s->p.gravity, s->p.domain_size, s->p.dt, keep,  \
-                       s->trav_tail, c, acc_flag, stack_limit, ord_rd, ord_wr, prev_groups)
+                       s->trav_tail, c, acc_flag, stack_limit)
         const bool walk_only = (s->p.flags & NBODY_FLAG_DEBUG_WALK_ONLY) != 0;
         // test aid: a node stack with 32 usable entries makes unexpanded push-backs and
         // depth-first single-node rounds the common case

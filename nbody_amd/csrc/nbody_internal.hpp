@@ -61,14 +61,7 @@ struct TravTail {
     float *vhx[2], *vhy[2], *vhz[2];
     float *vx[2], *vy[2], *vz[2];
     float *pot;
-    // Launch order of the traversal (see k_traverse): per kind of source tree (own / another
-    // handle's) and per buffer (read by this launch / written for the next one of that kind):
-    uint32_t *ord_ctrl;           // [2 kinds][2 buffers][TRAV_ORD_CTRL]: counts [8 XCDs][8 classes], then sum of list lengths / 16
-    uint32_t *ord_list;           // [2 kinds][2 buffers][8 XCDs][8 classes][ord_cap] groups
-    int32_t ord_cap;
 };
-constexpr int TRAV_CLASSES = 8;                     // cost classes the traversal orders its groups by
-constexpr int TRAV_ORD_CTRL = 8 * TRAV_CLASSES + 8;
 
 // Device-resident counters written by the build kernels (one int each).
 struct Counts {
@@ -171,9 +164,6 @@ struct Sim {
     NodeB *nodeB = nullptr;
     uint32_t *list_len = nullptr; // [ceil(n/group)]
     TravTail *trav_tail = nullptr;
-    uint32_t *trav_ord = nullptr;    // control words + group lists of the launch order (TravTail)
-    int trav_ord_buf[2] = {0, 0};    // per kind: the buffer the last launch of that kind wrote
-    int trav_ord_groups[2] = {0, 0}; // per kind: groups that launch covered (0 = no order yet)
     float *pot = nullptr;            // per-body potential sums (allocated by the first energy call)
     // LET exchange scratch
     float *let_boxes = nullptr;      // [LET_MAX_BOXES][LET_REC] device copy of caller-given boxes
