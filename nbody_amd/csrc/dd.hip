@@ -115,7 +115,11 @@ int ensure_remote(DD *d, size_t count)
     nbody_params p = d->own->p;
     const size_t want = std::max<size_t>(count + count / 4 + 1024, (size_t) d->own->cap / 2);
     p.num_points = (int32_t) std::min<size_t>(want, (size_t) (1 << 29) - 1);
-    p.max_num_codes_per_leaf = std::min(8, p.max_num_codes_per_leaf);
+    // small leaves: the records were exported at the resolution the NEAREST body of this domain
+    // needs, most groups are farther away and accept whole cells of them, which a leaf of many
+    // codes would force them to sum one by one (8 x 2,097,152 sphere: lists of 333 sources per
+    // group with 4 codes per leaf, 895 with 8, 1296 with 32)
+    p.max_num_codes_per_leaf = std::min(4, p.max_num_codes_per_leaf);
     p.num_steps_validator = 0;
     p.flags = 0;
     p.device_id = d->own->device;

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_frontier_bbox(int n, const Float4 *__re
     const int tid = threadIdx.x;
     const int F = seg[LET_MAX_T + 1];
     if (tid <= F) s_seg[tid] = seg[tid];
-    if (tid < LET_MAX_T * 6) (&s_box[0][0])[tid] = (tid % 6) < 3 ? 0x7f7fffffu : 0u;
+    for (int j = tid; j < LET_MAX_T * 6; j += 256) (&s_box[0][0])[j] = (j % 6) < 3 ? 0x7f7fffffu : 0u;
     __syncthreads();
     const int i = blockIdx.x * 256 + tid;
     const bool valid = i < n;
@@ -178,8 +178,8 @@ __global__ __launch_bounds__(256) void k_frontier_bbox(int n, const Float4 *__re
         for (int k = 0; k < 3; ++k) { atomicMin(&s_box[sg][k], v[k]); atomicMax(&s_box[sg][3 + k], v[k]); }
     }
     __syncthreads();
-    if (tid < F * 6) {
-        const int sl = tid / 6, k = tid % 6;
+    for (int j = tid; j < F * 6; j += 256) {
+        const int sl = j / 6, k = j % 6;
         const uint32_t b = s_box[sl][k];
         uint32_t *dst = reinterpret_cast<uint32_t *>(rec + (size_t) sl * LET_REC + k);
         if (k < 3) { if (b != 0x7f7fffffu) atomicMin(dst, b); }

@@ -26,7 +26,10 @@ constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 16;                      // elements per thread in compaction tiles
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 constexpr int LET_MAX_BOXES = 256;
-constexpr int LET_MAX_T = 32;                       // frontier records a domain advertises
+#ifndef NB_LET_MAX_T
+#define NB_LET_MAX_T 32
+#endif
+constexpr int LET_MAX_T = NB_LET_MAX_T;             // frontier records a domain advertises (< 256)
 constexpr int LET_REC = 12;                         // floats per frontier record
 constexpr int LET_MASK_DOMAINS = 32;                // remote domains per export launch (mask bits)
 #ifndef NB_TRAV_WAVES

@@ -22,7 +22,7 @@ else:
 keys = O.morton(ic["x"], ic["y"], ic["z"], 5.0, 21)
 order = np.argsort(keys, kind="stable")
 del keys
-T = nb.LET_MAX_RECORDS
+T = int(os.environ.get("DD_T", nb.LET_MAX_RECORDS))
 
 
 def params(m, **kw):
@@ -36,7 +36,7 @@ for r in range(W):
     s.set_state(ic["x"][idx], ic["y"][idx], ic["z"][idx], ic["m"][idx])
     s.set_traversal_range(0, 0)
     sims.append(s)
-imp = nb.Simulation(params(ppr, max_num_codes_per_leaf=8))
+imp = nb.Simulation(params(ppr, max_num_codes_per_leaf=int(os.environ.get("DD_LEAF", "4"))))
 
 
 def timed(f, sync):

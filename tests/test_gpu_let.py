@@ -44,7 +44,7 @@ class Domains:
             s.set_traversal_range(0, 0)                   # update() = build only
             self.sims.append(s)
             self.imports.append(nb.Simulation(_params(len(ic["x"]), bits, theta, eps, dt,
-                                                      max_num_codes_per_leaf=8)))
+                                                      max_num_codes_per_leaf=4)))
 
     def step(self):
         W, R = len(self.sims), self.records
