@@ -147,35 +147,39 @@ __global__ __launch_bounds__(256) void k_frontier_bbox(int n, const Float4 *__re
     if (tid <= F) s_seg[tid] = seg[tid];
     for (int j = tid; j < LET_MAX_T * 6; j += 256) (&s_box[0][0])[j] = (j % 6) < 3 ? 0x7f7fffffu : 0u;
     __syncthreads();
-    const int i = blockIdx.x * 256 + tid;
-    const bool valid = i < n;
-    int sg = 0;
-    uint32_t v[3] = {0, 0, 0};
-    if (valid) {
-        const Float4 p = posm[i];
-        v[0] = __float_as_uint(p.x); v[1] = __float_as_uint(p.y); v[2] = __float_as_uint(p.z);
-        int lo = 0, hi = F;   // largest sg with s_seg[sg] <= i
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (s_seg[mid] <= i) lo = mid; else hi = mid;
-        }
-        sg = lo;
-    }
-    const int sg0 = __builtin_amdgcn_readfirstlane(sg);
-    if (__all(valid && sg == sg0)) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            uint32_t mn = v[k], mx = v[k];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                mn = min(mn, (uint32_t) __shfl_xor((int) mn, o, 64));
-                mx = max(mx, (uint32_t) __shfl_xor((int) mx, o, 64));
+    // grid-stride over whole 256-particle chunks: a few hundred workgroups, each of which ends
+    // with one global atomic per bound of every node it met
+    for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
+        const int i = base + tid;
+        const bool valid = i < n;
+        int sg = 0;
+        uint32_t v[3] = {0, 0, 0};
+        if (valid) {
+            const Float4 p = posm[i];
+            v[0] = __float_as_uint(p.x); v[1] = __float_as_uint(p.y); v[2] = __float_as_uint(p.z);
+            int lo = 0, hi = F;   // largest sg with s_seg[sg] <= i
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_seg[mid] <= i) lo = mid; else hi = mid;
             }
-            if ((tid & 63) == 0) { atomicMin(&s_box[sg0][k], mn); atomicMax(&s_box[sg0][3 + k], mx); }
+            sg = lo;
         }
-    } else if (valid) {
+        const int sg0 = __builtin_amdgcn_readfirstlane(sg);
+        if (__all(valid && sg == sg0)) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { atomicMin(&s_box[sg][k], v[k]); atomicMax(&s_box[sg][3 + k], v[k]); }
+            for (int k = 0; k < 3; ++k) {
+                uint32_t mn = v[k], mx = v[k];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    mn = min(mn, (uint32_t) __shfl_xor((int) mn, o, 64));
+                    mx = max(mx, (uint32_t) __shfl_xor((int) mx, o, 64));
+                }
+                if ((tid & 63) == 0) { atomicMin(&s_box[sg0][k], mn); atomicMax(&s_box[sg0][3 + k], mx); }
+            }
+        } else if (valid) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { atomicMin(&s_box[sg][k], v[k]); atomicMax(&s_box[sg][3 + k], v[k]); }
+        }
     }
     __syncthreads();
     for (int j = tid; j < F * 6; j += 256) {
@@ -397,7 +401,7 @@ hipError_t launch_frontier(Sim *s, float *records_dev, int T)
 {
     hipLaunchKernelGGL(k_frontier_select, dim3(1), dim3(256), 0, s->stream, s->counts, s->n, T,
                        s->nodeB, s->nodeA, s->o_pb, s->o_pe, records_dev, s->let_seg);
-    hipLaunchKernelGGL(k_frontier_bbox, dim3((s->n + 255) / 256), dim3(256), 0, s->stream, s->n,
+    hipLaunchKernelGGL(k_frontier_bbox, dim3(std::min((s->n + 255) / 256, 1024)), dim3(256), 0, s->stream, s->n,
                        s->posm, s->let_seg, records_dev);
     return hipGetLastError();
 }
