@@ -14,6 +14,12 @@
 //                 and writes each digit run to its final place with consecutive lanes on
 //                 consecutive addresses.  Keys and indices are read once and written
 //                 once per pass: 2*(sizeof(KeyT)+4) bytes per element per pass.
+//   63-bit keys: the passes sort on the upper 40 bits only (5 passes instead of 8); elements
+//                 whose upper 40 bits agree -- a cell of domain / 2^13 -- are then ordered on
+//                 the remaining 24 bits where they lie: k_tiefix (one thread per run of equal
+//                 upper bits, ranked in registers; runs are 2-3 long in practice) and, for runs
+//                 longer than TIE_SHORT, k_tiefix_long (one wave per run, stable 8-bit LSD
+//                 passes within the run).  The result is the stable sort on the whole key.
 #include "dev_utils.hpp"
 #include "nbody_internal.hpp"
 
@@ -22,12 +28,13 @@
 #endif
 namespace nb {
 
-template <typename KeyT, int NPASS>
+// digits P0 .. NPASS-1 (ghist keeps one row of 256 per digit, rows below P0 stay zero)
+template <typename KeyT, int NPASS, int P0>
 __global__ __launch_bounds__(256) void k_sort_hist(const KeyT *__restrict__ keys, int n,
                                                    uint32_t *__restrict__ ghist)
 {
     __shared__ uint32_t h[NPASS * 256];
-    for (int j = threadIdx.x; j < NPASS * 256; j += 256) h[j] = 0;
+    for (int j = threadIdx.x + P0 * 256; j < NPASS * 256; j += 256) h[j] = 0;
     __syncthreads();
     // Four consecutive keys per thread: the keys arrive in the previous step's order, so their
     // upper digits repeat from one key to the next and equal neighbours share one LDS atomic.
@@ -38,7 +45,7 @@ __global__ __launch_bounds__(256) void k_sort_hist(const KeyT *__restrict__ keys
         for (int j = 0; j < 4; ++j) k[j] = i0 + j < n ? keys[i0 + j] : keys[i0];
         const int cntv = min(4, n - i0);
 #pragma unroll
-        for (int p = 0; p < NPASS; ++p) {
+        for (int p = P0; p < NPASS; ++p) {
             int run = 1;
             int d = (int) ((k[0] >> (8 * p)) & 255);
 #pragma unroll
@@ -53,9 +60,156 @@ __global__ __launch_bounds__(256) void k_sort_hist(const KeyT *__restrict__ keys
         }
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < NPASS * 256; j += 256) {
+    for (int j = threadIdx.x + P0 * 256; j < NPASS * 256; j += 256) {
         const uint32_t c = h[j];
         if (c) atomicAdd(&ghist[j], c);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Ordering of the elements whose upper key bits (above `low_bits`) agree, after the digit
+// passes have sorted on those upper bits.  Within such a run the elements are in index order
+// (the passes are stable and start from the identity), so a stable sort of the run on the
+// whole key yields the stable sort of everything.  A run only ever holds keys with the same
+// upper bits, whatever its sort is doing, so neighbouring runs can be found and sorted at the
+// same time.
+// ---------------------------------------------------------------------------
+constexpr int TIE_SHORT = 16;   // longest run one thread orders (in registers); longer ones take a wave
+
+constexpr int TIE_REG = TIE_SHORT;
+
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_tiefix(KeyT *keys, uint32_t *vals, int n, int low_bits,
+                                                uint32_t *__restrict__ long_runs,
+                                                uint32_t *long_count)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool in = i < n;
+    // own key and the TIE_REG - 1 that follow: from the neighbouring lanes where the wave has
+    // them (every lane takes part in the shuffles), from memory at the end of the wave
+    KeyT k[TIE_REG];
+    k[0] = in ? keys[i] : (KeyT) 0;
+#pragma unroll
+    for (int a = 1; a < TIE_REG; ++a) {
+        if (a == 2) {
+            // nearly always no key of the wave agrees with its successor: nothing starts here
+            const bool tie = in && i + 1 < n && (k[1] >> low_bits) == (k[0] >> low_bits);
+            if (!__any(tie)) return;
+        }
+        const uint32_t lo = (uint32_t) __shfl_down((int) (uint32_t) k[0], a, 64);
+        KeyT nb_key = lo;
+        if (sizeof(KeyT) == 8) {
+            const uint32_t hi = (uint32_t) __shfl_down((int) (uint32_t) ((uint64_t) k[0] >> 32), a, 64);
+            nb_key = (KeyT) (((uint64_t) hi << 32) | lo);
+        }
+        if (lane + a >= 64 && i + a < n) nb_key = keys[i + a];
+        k[a] = nb_key;
+    }
+    if (!in) return;
+    const KeyT h = k[0] >> low_bits;
+    if (i > 0 && (keys[i - 1] >> low_bits) == h) return;   // not the head of a run
+    int L = 1;
+#pragma unroll
+    for (int a = 1; a < TIE_REG; ++a)
+        if (L == a && i + a < n && (k[a] >> low_bits) == h) L = a + 1;
+    if (L == 1) return;
+    if (L == TIE_REG && i + L < n && (keys[i + L] >> low_bits) == h) {   // longer than a thread takes
+        long_runs[atomicAdd(long_count, 1u)] = (uint32_t) i;
+        return;
+    }
+    // rank every element of the run among the others (equal keys by position) and move those
+    // that are out of place; all reads come before the writes
+    uint32_t v[TIE_REG];
+#pragma unroll
+    for (int a = 0; a < TIE_REG; ++a) v[a] = a < L ? vals[i + a] : 0u;
+#pragma unroll
+    for (int a = 0; a < TIE_REG; ++a) {
+        if (a < L) {
+            int r = 0;
+#pragma unroll
+            for (int b = 0; b < TIE_REG; ++b)
+                if (b < L) r += (k[b] < k[a] || (k[b] == k[a] && b < a)) ? 1 : 0;
+            if (r != a) { keys[i + r] = k[a]; vals[i + r] = v[a]; }
+        }
+    }
+}
+
+// One wave per long run: low_bits / 8 stable 8-bit LSD passes over the run, between the run's
+// place in the sorted buffers (k0, v0) and the same place in the other buffer pair (k1, v1),
+// whose contents are dead after the digit passes.  64 elements at a time, in order: lanes with
+// the same digit rank themselves by ballot matching, the digit's running offset lives in LDS.
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_tiefix_long(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1,
+                                                     int n, int low_bits,
+                                                     const uint32_t *__restrict__ long_runs,
+                                                     const uint32_t *long_count)
+{
+    __shared__ uint32_t s_base[4][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t *base = s_base[w];
+    const int nruns = (int) __hip_atomic_load(long_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int r = blockIdx.x * 4 + w; r < nruns; r += gridDim.x * 4) {
+        const int start = (int) long_runs[r];
+        const KeyT h = k0[start] >> low_bits;
+        int L = 0;   // length of the run: first position whose upper bits differ
+        while (true) {
+            const int j = start + L + lane;
+            const unsigned long long same = __ballot(j < n && (k0[j] >> low_bits) == h);
+            if (same != ~0ull) { L += __ffsll((long long) ~same) - 1; break; }
+            L += 64;
+        }
+        KeyT *ks = k0 + start, *kd = k1 + start;
+        uint32_t *vs = v0 + start, *vd = v1 + start;
+        const int passes = low_bits / 8;
+        for (int p = 0; p < passes; ++p) {
+            const int shift = 8 * p;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) base[lane * 4 + q] = 0;
+            __builtin_amdgcn_wave_barrier();
+            for (int j = lane; j < L; j += 64) atomicAdd(&base[(uint32_t) (ks[j] >> shift) & 255u], 1u);
+            __builtin_amdgcn_wave_barrier();
+            // exclusive scan of the 256 counts: four bins per lane
+            uint32_t c[4], sum = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { c[q] = base[lane * 4 + q]; sum += c[q]; }
+            uint32_t off = wave_incl_scan_u32(sum) - sum;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { base[lane * 4 + q] = off; off += c[q]; }
+            __builtin_amdgcn_wave_barrier();
+            for (int j0 = 0; j0 < L; j0 += 64) {
+                const int j = j0 + lane;
+                const bool valid = j < L;
+                const KeyT kk = valid ? ks[j] : (KeyT) 0;
+                const uint32_t vv = valid ? vs[j] : 0u;
+                const uint32_t d = (uint32_t) (kk >> shift) & 255u;
+                unsigned long long m = __ballot(valid);
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const bool bit = (d >> b) & 1u;
+                    const unsigned long long bb = __ballot(bit);
+                    m &= bit ? bb : ~bb;
+                }
+                const uint32_t rnk = (uint32_t) mbcnt(m);
+                const uint32_t at = base[d] + rnk;
+                __builtin_amdgcn_wave_barrier();
+                if (valid) {
+                    kd[at] = kk;
+                    vd[at] = vv;
+                    if (rnk == 0) base[d] = at + (uint32_t) __popcll(m);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            // what this pass stored is read by other lanes of the wave in the next one
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            KeyT *tk = ks; ks = kd; kd = tk;
+            uint32_t *tv = vs; vs = vd; vd = tv;
+        }
+        if (passes & 1) {   // the run ended up in the other buffer pair
+            for (int j = lane; j < L; j += 64) { kd[j] = ks[j]; vd[j] = vs[j]; }
+        }
     }
 }
 
@@ -175,7 +329,12 @@ void launch_rank_pass(const uint32_t *keys, uint32_t *keys_out, uint32_t *vals_o
                        hist, status, status + (size_t) grid * 256, ticket, err);
 }
 
-template <typename KeyT, int NPASS>
+#ifndef NB_SORT_SKIP_DIGITS
+#define NB_SORT_SKIP_DIGITS 3
+#endif
+
+// P0 = low digits left to the tie fix (0 = every digit gets a pass)
+template <typename KeyT, int NPASS, int P0>
 static hipError_t sort_impl(Sim *s)
 {
     const int n = s->n;
@@ -188,15 +347,15 @@ static hipError_t sort_impl(Sim *s)
     uint32_t *tickets = s->ghist + 8 * 256;
     uint32_t *status = tickets + 16;
     const int hgrid = std::min(std::max((n + 4095) / 4096, 1), NB_HIST_GRID);  // few blocks: the hot bins take one atomic per block
-    hipLaunchKernelGGL((k_sort_hist<KeyT, NPASS>), dim3(hgrid), dim3(256), 0, s->stream,
+    hipLaunchKernelGGL((k_sort_hist<KeyT, NPASS, P0>), dim3(hgrid), dim3(256), 0, s->stream,
                        (const KeyT *) s->keys[0], n, s->ghist);
     int in = 0;
-    for (int p = 0; p < NPASS; ++p) {
+    for (int p = P0; p < NPASS; ++p) {
         const KeyT *kin = (const KeyT *) s->keys[in];
         KeyT *kout = (KeyT *) s->keys[in ^ 1];
         uint32_t *st = status + (size_t) p * rows * 256;
         uint32_t *gst = st + (size_t) tiles * 256;
-        if (p == 0)
+        if (p == P0)
             hipLaunchKernelGGL((k_sort_pass<KeyT, SORT_ITEMS, true>), dim3(tiles), dim3(256), 0,
                                s->stream, kin, (const uint32_t *) nullptr, kout, s->vals[in ^ 1],
                                (uint32_t *) nullptr, (const int32_t *) nullptr, n, 8 * p,
@@ -208,13 +367,25 @@ static hipError_t sort_impl(Sim *s)
                                8 * p, s->ghist + p * 256, st, gst, tickets + p, &s->counts->err);
         in ^= 1;
     }
-    s->sorted_buf = in;  // NPASS is even: back in buffer 0
+    s->sorted_buf = in;
+    if (P0 > 0) {
+        // runs of equal upper bits: heads of the long ones are listed in the (not yet used)
+        // unique-key buffer, counted in a spare ticket word of the block zeroed above
+        uint32_t *long_runs = (uint32_t *) s->unique;
+        uint32_t *long_count = tickets + 8;
+        KeyT *k0 = (KeyT *) s->keys[in], *k1 = (KeyT *) s->keys[in ^ 1];
+        hipLaunchKernelGGL(k_tiefix<KeyT>, dim3((n + 255) / 256), dim3(256), 0, s->stream, k0,
+                           s->vals[in], n, 8 * P0, long_runs, long_count);
+        hipLaunchKernelGGL(k_tiefix_long<KeyT>, dim3(std::min((n / TIE_SHORT + 3) / 4 + 1, 256)), dim3(256), 0,
+                           s->stream, k0, s->vals[in], k1, s->vals[in ^ 1], n, 8 * P0,
+                           (const uint32_t *) long_runs, (const uint32_t *) long_count);
+    }
     return hipGetLastError();
 }
 
 hipError_t launch_sort(Sim *s)
 {
-    return s->key_bytes == 4 ? sort_impl<uint32_t, 4>(s) : sort_impl<uint64_t, 8>(s);
+    return s->key_bytes == 4 ? sort_impl<uint32_t, 4, 0>(s) : sort_impl<uint64_t, 8, NB_SORT_SKIP_DIGITS>(s);
 }
 
 }  // namespace nb

@@ -117,6 +117,53 @@ def test_all_particles_on_one_code():
     assert not st["ax"].any() and not st["ay"].any()  # coincident particles: zero force, no NaN
 
 
+@pytest.mark.parametrize("fp64", [False, True])
+def test_sort_with_long_runs_of_equal_upper_key_bits(fp64):
+    """63-bit keys are sorted by digit passes on their upper 40 bits and the runs of equal upper
+    bits are ordered afterwards: a few per thread, long ones one wave each.  Thousands of
+    particles inside one cell of domain / 2^13 (keys that differ only in the low 24 bits),
+    thousands on one point (equal keys: index order must survive), pairs and triples, and a
+    background: codes and permutation must be the oracle's stable sort, bit for bit."""
+    rng = np.random.default_rng(5)
+    n = 60000
+    dt_ = np.float64 if fp64 else np.float32
+    p = rng.uniform(0.5, 4.5, (n, 3))
+    cell = 5.0 / 8192
+    corner = np.floor(np.array([1.7, 2.9, 3.3]) / cell) * cell
+    p[:9000] = corner + rng.uniform(0.02, 0.98, (9000, 3)) * cell      # one cell: one long run
+    p[9000:12500] = np.array([3.125, 0.625, 2.0])                       # one point: equal keys
+    for j in range(40):                                                 # 40 cells with 33..72 particles
+        c = np.floor(rng.uniform(1, 4, 3) / cell) * cell
+        k = 33 + j
+        a = 12500 + 80 * j
+        p[a:a + k] = c + rng.uniform(0.05, 0.95, (k, 3)) * cell
+    a = 16000                                                           # 3000 cells with 2..5 particles
+    for j in range(3000):
+        c = np.floor(rng.uniform(1, 4, 3) / cell) * cell
+        k = 2 + j % 4
+        p[a:a + k] = c + rng.uniform(0.05, 0.95, (k, 3)) * cell
+        a += k
+    perm0 = rng.permutation(n)
+    p = p[perm0]
+    x, y, z = (np.ascontiguousarray(p[:, i], dt_) for i in range(3))
+    m = np.ones(n, dt_)
+    flags = nb.FLAG_FP64 if fp64 else 0
+    with new_sim(n, morton_bits=21, flags=flags) as sim:
+        sim.set_state(x, y, z, m)
+        gpu = sim.get_octree()
+        sim.update()                     # a second sort, from the sorted order
+        gpu2 = sim.get_octree()
+    ref = (O.full_build_dp if fp64 else O.full_build)(x, y, z, m, 5.0, 21, 32)
+    top = ref["codes_sorted"] >> np.uint64(24)
+    runs = np.diff(np.flatnonzero(np.r_[True, top[1:] != top[:-1], True]))
+    assert runs.max() >= 9000 and (runs > 32).sum() >= 40 and ((runs > 1) & (runs <= 32)).sum() >= 2500
+    assert np.array_equal(gpu["codes_sorted"], ref["codes_sorted"])
+    assert np.array_equal(gpu["perm"], ref["perm"])
+    assert_build_equal(gpu, ref)
+    assert np.array_equal(gpu2["codes_sorted"], ref["codes_sorted"])
+    assert np.array_equal(gpu2["perm"], np.arange(n))
+
+
 def oracle_after_kick_drift(ic, dt, domain, bits, max_codes):
     """State after spawn + the kick-drift of the first update (accelerations are still 0)."""
     ref0 = O.full_build(ic["x"], ic["y"], ic["z"], ic["m"], domain, bits, max_codes)
@@ -493,11 +540,11 @@ def test_group_of_32_ragged_sizes(n, bits, theta):
 
 
 @pytest.mark.parametrize("group", [64, 32])
-def test_heavy_groups_are_started_first_and_done_once(group):
+def test_spread_out_groups_with_long_lists(group):
     """A thin slab of bodies across a large cell boundary (x = 2.5) sits at the end of the Morton
     order in groups that are spread out in space: their source lists are several times the
-    mean.  From the second launch on the traversal starts such groups ahead of the others; every
-    group must still be done exactly once, with the same list and the same forces."""
+    mean (the deepest use of the node stack and of the leaf batches).  Three launches over the
+    same state must give the same lists and bitwise the same forces."""
     rng = np.random.default_rng(11)
     n = 300000
     p = rng.uniform(2.0, 2.5, (n, 3)).astype(np.float32)
@@ -517,7 +564,7 @@ def test_heavy_groups_are_started_first_and_done_once(group):
     ref = O.full_build(p[:, 0], p[:, 1], p[:, 2], m, 5.0, 21, 32)
     ax, ay, az, ll = O.traverse(ref["tree"], ref["com"], ref["xs"], ref["ys"], ref["zs"], ref["ms"],
                                 group, theta, eps, 1.0, 5.0)
-    assert ll.max() > 2.2 * ll.mean()             # above the traversal's "twice the mean" mark
+    assert ll.max() > 2.2 * ll.mean()
     for got in lists:
         assert np.array_equal(got, ll)
     assert np.array_equal(accs[0], accs[1]) and np.array_equal(accs[1], accs[2])
