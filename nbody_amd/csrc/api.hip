@@ -49,7 +49,7 @@ void free_all(Sim *s)
         F(s->x[i]); F(s->y[i]); F(s->z[i]); F(s->m[i]); F(s->vhx[i]); F(s->vhy[i]); F(s->vhz[i]);
         F(s->vx[i]); F(s->vy[i]); F(s->vz[i]); F(s->id[i]); F(s->keys[i]); F(s->vals[i]);
     }
-    F(s->ax); F(s->ay); F(s->az); F(s->posm); F(s->posm2); F(s->ghist); F(s->zero_block); F(s->com_counter);
+    F(s->ax); F(s->ay); F(s->az); F(s->posm); F(s->posm2); F(s->zero_block); F(s->com_counter);
     F(s->counts); F(s->unique); F(s->first_pt); F(s->lfc); F(s->leaf_key); F(s->rt_pd);
     F(s->rt_level); F(s->rt_lb); F(s->rt_le); F(s->rt_left); F(s->rt_right); F(s->depth_key);
     F(s->bfs); F(s->octid); F(s->o_depth); F(s->o_first_child); F(s->o_num_children); F(s->o_lb);
@@ -113,19 +113,18 @@ int alloc_all(Sim *s)
         NB_HIP(s, hipMemsetAsync(s->posm2, 0, posm2_floats * 4, s->stream));
     }
 
-    // sort scratch: ghist[8*256] | tickets[16] | status[P][tiles][256]
+    // Scratch zeroed once per step, one allocation so that one memset does it:
+    //   build part: tickets[16] | scan_status[2][T] | dhist[256] | rank_status[R][256]
+    //   sort part : ghist[8*256] | tickets[16] | status[P][rows][256]
     s->sort_tiles = (int) ((n + SORT_TILE - 1) / SORT_TILE);
     const int passes = s->key_bytes == 4 ? 4 : 8;
     s->sort_status_bytes = (8 * 256 + 16 + (size_t) passes * sort_status_rows(s->sort_tiles) * 256) * sizeof(uint32_t);
-    NB_HIP(s, hipMalloc((void **) &s->ghist, s->sort_status_bytes));
-
-    // build scratch zeroed once per build: tickets[16] | scan_status[2][T] | dhist[256] |
-    // rank_status[R][256]
     s->max_scan_tiles = (int) ((n + 1023) / 1024);  // smallest compaction tile is 1024
     s->rank_tiles = (int) ((2 * n + SORT_TILE - 1) / SORT_TILE);
     const size_t zwords = 16 + 2 * (size_t) s->max_scan_tiles + 256 + (size_t) sort_status_rows(s->rank_tiles) * 256;
     s->zero_bytes = (zwords * 4 + 15) / 16 * 16;
-    NB_HIP(s, hipMalloc((void **) &s->zero_block, s->zero_bytes));
+    NB_HIP(s, hipMalloc((void **) &s->zero_block, s->zero_bytes + s->sort_status_bytes));
+    s->ghist = (uint32_t *) (s->zero_block + s->zero_bytes);
     uint32_t *zw = (uint32_t *) s->zero_block;
     s->tickets = zw;
     s->scan_status = zw + 16;

@@ -340,9 +340,11 @@ static hipError_t sort_impl(Sim *s)
     const int n = s->n;
     const int tiles = (n + SORT_TILE - 1) / SORT_TILE;   // <= s->sort_tiles (sized for cap)
     const int rows = sort_status_rows(tiles);            // tile rows + group rows of one pass
-    const size_t zbytes = (8 * 256 + 16 + (size_t) NPASS * rows * 256) * sizeof(uint32_t);
-    hipError_t e = hipMemsetAsync(s->ghist, 0, zbytes, s->stream);
+    const size_t zbytes = (8 * 256 + 16 + (size_t) (NPASS - P0) * rows * 256) * sizeof(uint32_t);
+    // one memset for this sort's scratch and for the tree build's, which lies just before it
+    hipError_t e = hipMemsetAsync(s->zero_block, 0, s->zero_bytes + zbytes, s->stream);
     if (e != hipSuccess) return e;
+    s->build_scratch_zeroed = true;
     // layout of the zeroed block: ghist[8*256] | tickets[8] (+pad to 16) | status[P][rows][256]
     uint32_t *tickets = s->ghist + 8 * 256;
     uint32_t *status = tickets + 16;
@@ -353,7 +355,7 @@ static hipError_t sort_impl(Sim *s)
     for (int p = P0; p < NPASS; ++p) {
         const KeyT *kin = (const KeyT *) s->keys[in];
         KeyT *kout = (KeyT *) s->keys[in ^ 1];
-        uint32_t *st = status + (size_t) p * rows * 256;
+        uint32_t *st = status + (size_t) (p - P0) * rows * 256;
         uint32_t *gst = st + (size_t) tiles * 256;
         if (p == P0)
             hipLaunchKernelGGL((k_sort_pass<KeyT, SORT_ITEMS, true>), dim3(tiles), dim3(256), 0,

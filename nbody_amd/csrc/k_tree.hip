@@ -419,8 +419,11 @@ static hipError_t build_impl(Sim *s)
 {
     const int n = s->n;
     hipStream_t st = s->stream;
-    hipError_t e = hipMemsetAsync(s->zero_block, 0, s->zero_bytes, st);
+    // tickets, look-back words, depth histogram start at zero: the sort that precedes a build
+    // has cleared them together with its own scratch
+    hipError_t e = s->build_scratch_zeroed ? hipSuccess : hipMemsetAsync(s->zero_block, 0, s->zero_bytes, st);
     if (e != hipSuccess) return e;
+    s->build_scratch_zeroed = false;
     const int scan_grid = (n + SCAN_TILE - 1) / SCAN_TILE;
     const KeyT *sorted = (const KeyT *) s->keys[s->sorted_buf];
     hipLaunchKernelGGL(k_unique<KeyT>, dim3(scan_grid), dim3(SCAN_THREADS), 0, st, sorted, n,

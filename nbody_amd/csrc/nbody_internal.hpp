@@ -133,7 +133,8 @@ struct Sim {
     int sort_tiles = 0;
 
     // scratch zeroed once per build (tickets, look-back words, counters, histograms)
-    uint8_t *zero_block = nullptr;
+    uint8_t *zero_block = nullptr;   // build part, then the sort's part (ghist points into it)
+    bool build_scratch_zeroed = false;  // set by the sort's memset, consumed by the build
     size_t zero_bytes = 0;
     uint32_t *tickets = nullptr;      // [8]
     uint32_t *scan_status = nullptr;  // [3][max_scan_tiles]
