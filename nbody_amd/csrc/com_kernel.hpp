@@ -23,6 +23,10 @@
 // Hand-off in the climb: sums are stored write-through (agent-scope atomic stores), the storing
 // wave drains its stores (s_waitcnt vmcnt(0)) before the agent-scope counter add, and the last
 // arriver reads the sums with agent-scope atomic loads -- only after its add has returned.
+// The sums never sit in a cache the reader does not see, so no cache maintenance is needed;
+// an acquire-release counter add instead (the compiler then writes back and invalidates the
+// XCD's L2 around every add) was measured at 0.30 ms against 0.064 ms for this kernel at
+// 2,097,152 particles.
 // Leaves that hang directly off a node above the local roots start the climb themselves.
 #pragma once
 #include "dev_utils.hpp"
