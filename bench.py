@@ -41,11 +41,12 @@ EPS = 0.1
 DT = 1e-6
 FLOP_PER_INTERACTION = 20          # GPU-Gems/Nyland convention for one softened pair force
 # algorithmic bytes per particle of integrate+sort+permute+build+COM, by key width: kick-drift
-# and encode 36 R + 28/32 W; all digit histograms in one key read 4/8; 4/8 digit passes of
-# 16/24 (key + index, read and written once); permute 36 R + 64 W; unique 12/20; tree kernels
-# (leaves, radix, depth, rank, emit) ~16; centre of mass 20
-BUILD_BYTES_PER_PARTICLE = {10: 64 + 4 + 4 * 16 + 100 + 12 + 16 + 20,    # 30-bit keys: 280
-                            21: 68 + 8 + 8 * 24 + 100 + 20 + 16 + 20}    # 63-bit keys: 424
+# and encode 36 R + 28/32 W; the digit histograms in one key read 4/8; 4/5 digit passes of
+# 16/24 (key + index, read and written once; 63-bit keys are sorted on their upper 40 bits and
+# the rare ties ordered in place, one more key read); permute 36 R + 64 W; unique 12/20; tree
+# kernels (leaves, radix, depth, rank, emit) ~16; centre of mass 20
+BUILD_BYTES_PER_PARTICLE = {10: 64 + 4 + 4 * 16 + 100 + 12 + 16 + 20,        # 30-bit keys: 280
+                            21: 68 + 8 + 5 * 24 + 8 + 100 + 20 + 16 + 20}    # 63-bit keys: 360
 PEAK_FP32_TFLOPS = 157.3           # MI355X FP32 vector peak
 PEAK_FP64_TFLOPS = 78.6            # MI355X FP64 vector peak
 PEAK_HBM_GBS = 8000.0              # MI355X HBM3E peak
