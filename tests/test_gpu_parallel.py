@@ -129,6 +129,15 @@ def test_domain_decomposition_single_rank_is_a_plain_step(single_rank_group):
         assert np.array_equal(sa[k], sb[k]), k
 
 
+@pytest.mark.parametrize("flags", [nb.FLAG_FP64, nb.FLAG_FIT_KEYS])
+def test_domain_decomposition_refuses_handles_it_cannot_step(single_rank_group, flags):
+    """The exchange is float-only and every rank must share one key cube: a double handle and a
+    handle with a fitted key domain are refused when the stepper is created, not later."""
+    with nb.Simulation(nb.Params(num_points=1000, device_id=0, flags=flags)) as sim:
+        with pytest.raises(RuntimeError, match="nbody_dd_create failed"):
+            parallel.DomainDecomposition(sim, "cuda:0")
+
+
 def test_torch_comm_callbacks_single_rank_nccl(single_rank_group):
     """The two collectives the library calls back into, over RCCL with one rank: raw device
     pointers, the library's own stream, scattered and packed layouts."""
