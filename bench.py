@@ -54,6 +54,29 @@ SUSTAINED_CLOCK_GHZ = 2.0          # shader clock measured inside k_traverse (pr
 REFERENCE_MS_PER_STEP = 150.0      # reference README, RTX 500 Ada, 2,097,152 particles, theta=0.6
 
 
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+    """Libraries below print to stdout on their own (RCCL's \"Librccl path\", gloo's connection
+    lines): everything written to file descriptor 1 goes to stderr until emit() restores it, so
+    that the one JSON line is all that stdout ever carries."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    sys.stdout.flush()
+    if _REAL_STDOUT is not None:
+        os.dup2(_REAL_STDOUT, 1)
+    print(json.dumps(obj), flush=True)
+    if _REAL_STDOUT is not None:
+        os.dup2(2, 1)
+
+
 def cpu_baseline(ic, bits, steps=1, eps=EPS):
     """The host oracle (same algorithm, same parameters) timed on this machine's cores on
     `steps` steps of the full 2,097,152-particle workload."""
@@ -193,7 +216,7 @@ def run_direct(args, world, rank, local_rank):
             cpu = {"value": round(nt * float(n) / tc), "unit": "interactions/s",
                    "cores": O.lib().orc_num_threads(), "kind": "port",
                    "sample": f"{nt} target bodies x {n} sources ({tc:.1f} s), OpenMP over targets"}
-        print(json.dumps({
+        emit(({
             "metric": "interactions/s, O(N^2) direct sum", "value": round(rate), "unit": "interactions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed * 1e3 / K, 3), "higher_is_better": True, "scaling": "strong",
@@ -240,6 +263,7 @@ def main():
     ap.add_argument("--walk-only", action="store_true",
                     help="profiling aid: skip the force arithmetic (results meaningless)")
     args = ap.parse_args()
+    quiet_stdout()
 
     import numpy as np
     import torch
@@ -581,7 +605,7 @@ def main():
             out["other_precision"] = f64
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ic, args.morton_bits, steps=5, eps=eps)
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
