@@ -520,6 +520,31 @@ def main():
                "traversal_ms": round(t7["ms_traverse"] / 20, 4),
                "build_ms": round((t7["ms_integrate"] + t7["ms_sort"] + t7["ms_build"] + t7["ms_com"]) / 20, 4),
                "interactions_per_step": round(t7["interactions"] / 20)}
+    disk = None
+    if world == 1 and not args.no_alt_bits and not args.walk_only:
+        # BASELINE.json configs[1]: the reference's ~27 ms/frame case, for the record
+        nd = 524_288
+        icd = nb.sample_ic(nb.IC_DISK, nd, 42)
+        pd_ = nb.Params(num_points=nd, max_num_codes_per_leaf=32, traversal_group_size=group, theta=0.75,
+                        dt=1e-4, gravity=1.0, softening_factor=1e-3, domain_size=5.0,
+                        morton_bits=args.morton_bits, device_id=local_rank, flags=nb.FLAG_TIMING)
+        with nb.Simulation(pd_) as s8:
+            s8.set_state(icd["x"], icd["y"], icd["z"], icd["m"], icd["vx"], icd["vy"], icd["vz"])
+            s8.step(5)
+            s8.get_timings()
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            s8.step(50)
+            s8.sync()
+            tb = time.perf_counter()
+            t8 = s8.get_timings()
+        disk = {"workload": "524,288-particle self-gravitating disk, theta=0.75, eps=1e-3, dt=1e-4 "
+                            "(the reference's ~27 ms/frame configuration)",
+                "ms_per_step": round((tb - ta) * 1e3 / 50, 4),
+                "traversal_ms": round(t8["ms_traverse"] / 50, 4),
+                "build_ms": round((t8["ms_integrate"] + t8["ms_sort"] + t8["ms_build"] + t8["ms_com"]) / 50, 4),
+                "interactions_per_step": round(t8["interactions"] / 50),
+                "traversal_tflops": round(FLOP_PER_INTERACTION * t8["interactions"] / (t8["ms_traverse"] * 1e-3) / 1e12, 2)}
     direct = None
     if world == 1 and not args.no_direct_sum and not args.walk_only:
         direct = direct_sum_block(args.no_cpu_baseline)
@@ -625,6 +650,8 @@ def main():
             out["other_key_width"] = alt
         if fit is not None:
             out["fitted_30bit_keys"] = fit
+        if disk is not None:
+            out["disk_524k"] = disk
         if direct is not None:
             out["direct_sum"] = direct
         if g32 is not None:
