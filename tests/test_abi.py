@@ -86,3 +86,18 @@ def test_no_cpu_fallback_without_gpu():
         assert "status 2" in str(e)
     else:
         raise AssertionError("Simulation() must fail without a GPU")
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    """No CPU fallback anywhere: without a GPU the benchmark says so and prints no result line."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 2
+    assert r.stdout.strip() == ""
+    assert "needs a GPU" in r.stderr
