@@ -92,6 +92,7 @@ def test_bench_refuses_to_run_without_a_gpu():
     """No CPU fallback anywhere: without a GPU the benchmark says so and prints no result line."""
     import subprocess
     import sys
+    import pytest
     import torch
     if torch.cuda.is_available():
         pytest.skip("a GPU is present")
