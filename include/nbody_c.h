@@ -402,6 +402,36 @@ int nbody_let_export_dev(nbody_t *sim, const float *frontiers_dev, int32_t ndoma
 int nbody_set_sources_dev(nbody_t *sim, const float *posm_dev, int32_t count);
 int nbody_traverse_from(nbody_t *sim, nbody_t *sources, int32_t accumulate);
 
+/* The same exchange with the essential part of a tree shipped AS A TREE, so that the receiver
+ * neither sorts nor builds anything for it and walks own and imported nodes in ONE traversal
+ * (what nbody_dd_step does; no counterpart in the single-GPU reference).
+ * nbody_let_export_tree_dev: as nbody_let_export_dev, but domain d receives a pruned copy of this
+ *   handle's octree: the REACHED nodes (no ancestor passes d's opening criterion) in breadth-first
+ *   order, children contiguous.  Segment d starts at out_dev + capacity_bytes * d and holds
+ *   counts_dev[2d] node records of 32 bytes -- (com x, y, z, mass | size, first, count, meta), the
+ *   traversal's own node layout, `first` counted from the segment's first node (inner nodes) or
+ *   first particle record (leaves, meta = 0x80000000) -- followed by counts_dev[2d+1] particle
+ *   records (x,y,z,m).  A reached inner node that passes the criterion is a leaf of one particle
+ *   record, its (centre of mass, mass).  If 32 * nodes + 16 * records > capacity_bytes nothing
+ *   is written for that domain (call again with more room).  capacity_bytes: multiple of 16.
+ * nbody_import_trees_dev: hang `ncopies` such segments (device memory, complete on the handle's
+ *   stream; copy r at recv_dev + byte_offset[r] with node_count[r] nodes and record_count[r]
+ *   records, host arrays; empty copies allowed) behind the handle's own tree until the next
+ *   nbody_update().  Queued on the handle's stream; grows the handle's node and particle arrays
+ *   when the copies need more room than they have (that synchronises).
+ * nbody_traverse_forest: accelerations of the particles of groups [group_begin, group_end) of the
+ *   sorted order (group_end = -1: every group) in one launch, no velocity kick
+ *   (nbody_finish_step()); what = 0: due to the own tree alone, 1: due to the own tree AND the
+ *   imported copies in one walk, 2: due to the copies alone, ADDED to what ax/ay/az hold (for
+ *   groups that were walked with what = 0 before the copies had arrived). */
+int nbody_let_export_tree_dev(nbody_t *sim, const float *frontiers_dev, int32_t ndomains,
+                              int32_t records_per_domain, int32_t skip_domain, void *out_dev,
+                              size_t capacity_bytes, int32_t *counts_dev);
+int nbody_import_trees_dev(nbody_t *sim, const void *recv_dev, int32_t ncopies,
+                           const size_t *byte_offset, const int32_t *node_count,
+                           const int32_t *record_count);
+int nbody_traverse_forest(nbody_t *sim, int32_t what, int32_t group_begin, int32_t group_end);
+
 /* Host-side sampler for a slice of a particle set: particles [first, first + count) of n_total
  * (nbody_sample_ic = first 0, count n_total).  A particle's draws depend only on (seed, its
  * index in the whole set), so processes that sample disjoint slices hold, together, exactly
@@ -456,11 +486,13 @@ int nbody_dd_step(nbody_dd_t *dd);
  * widened; splitters[size] = 2^bits), and counters of the last step.  Pointers may be NULL. */
 typedef struct nbody_dd_stats {
     int64_t n_local;            /* particles this rank owns                       */
-    int64_t records_sent;       /* LET records exported in the last step          */
-    int64_t records_received;   /* LET records imported in the last step          */
+    int64_t records_sent;       /* particle records (16 bytes) exported in the last step */
+    int64_t records_received;   /* particle records imported in the last step     */
     int64_t migrated_out;       /* particles given away by the last rebalance     */
     int32_t frontier_records;   /* frontier nodes advertised in the last step     */
-    int32_t export_capacity;    /* records per destination the export buffer holds */
+    int32_t export_capacity;    /* 16-byte units per destination the export buffer holds */
+    int64_t nodes_sent;         /* node records (32 bytes) exported in the last step */
+    int64_t nodes_received;     /* node records imported in the last step            */
 } nbody_dd_stats;
 int nbody_dd_get_stats(nbody_dd_t *dd, nbody_dd_stats *out, uint64_t *splitters);
 /* Pure host function behind nbody_dd_rebalance: cut positions from a global histogram.

@@ -84,7 +84,7 @@ class CComm(C.Structure):
 class CDDStats(C.Structure):
     _fields_ = [("n_local", C.c_int64), ("records_sent", C.c_int64), ("records_received", C.c_int64),
                 ("migrated_out", C.c_int64), ("frontier_records", C.c_int32),
-                ("export_capacity", C.c_int32)]
+                ("export_capacity", C.c_int32), ("nodes_sent", C.c_int64), ("nodes_received", C.c_int64)]
 
 
 LET_REC = 12          # floats per frontier record: lo xyz, hi xyz, com xyz, mass, size, count
@@ -113,6 +113,7 @@ EXPORTS = [
     "nbody_dd_create", "nbody_dd_destroy", "nbody_dd_last_error", "nbody_dd_spawn",
     "nbody_dd_rebalance", "nbody_dd_step", "nbody_dd_get_stats", "nbody_dd_choose_edges",
     "nbody_dd_refine_edge", "nbody_get_key_domain",
+    "nbody_let_export_tree_dev", "nbody_import_trees_dev", "nbody_traverse_forest",
 ]
 
 _lib = None
@@ -191,6 +192,11 @@ def load_library() -> C.CDLL:
     lib.nbody_let_frontier_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     lib.nbody_let_export_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                          C.c_void_p, C.c_int32, C.c_void_p]
+    lib.nbody_let_export_tree_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                              C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.nbody_import_trees_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_size_t),
+                                           C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.nbody_traverse_forest.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     lib.nbody_sample_ic_range.argtypes = [C.c_int, C.c_int64, C.c_int32, C.c_int64, C.c_uint64,
                                           C.c_float, C.c_float, C.c_float, C.c_float] + [fp] * 7
     lib.nbody_dd_create.argtypes = [C.c_void_p, C.POINTER(CComm), C.POINTER(C.c_void_p)]
@@ -549,6 +555,27 @@ class Simulation:
             raise CapacityError(counts)
         self._check(rc)
         return counts
+
+    def let_export_tree_dev(self, frontiers_dev_ptr: int, ndomains: int, records_per_domain: int,
+                            skip_domain: int, out_dev_ptr: int, capacity_bytes: int, counts_dev_ptr: int):
+        """Pruned copies of this handle's tree, one per remote domain (nbody_let_export_tree_dev):
+        counts_dev = 2 int32 per domain (node records of 32 bytes, then particle records of 16)."""
+        self._check(self._lib.nbody_let_export_tree_dev(self._h, frontiers_dev_ptr, ndomains,
+                                                        records_per_domain, skip_domain, out_dev_ptr,
+                                                        capacity_bytes, counts_dev_ptr))
+
+    def import_trees_dev(self, recv_dev_ptr: int, byte_offsets, node_counts, record_counts):
+        """Hangs the given tree copies (device memory) behind the own tree until the next update()."""
+        k = len(node_counts)
+        off = (C.c_size_t * max(k, 1))(*[int(v) for v in byte_offsets])
+        nn = (C.c_int32 * max(k, 1))(*[int(v) for v in node_counts])
+        nr = (C.c_int32 * max(k, 1))(*[int(v) for v in record_counts])
+        self._check(self._lib.nbody_import_trees_dev(self._h, recv_dev_ptr, k, off, nn, nr))
+
+    def traverse_forest(self, what: int = 1, group_begin: int = 0, group_end: int = -1):
+        """Forces on groups [group_begin, group_end) (-1: all) from the own tree (what=0), the own
+        tree and the imported copies in one walk (1), or the copies alone, added (2); no kick."""
+        self._check(self._lib.nbody_traverse_forest(self._h, what, group_begin, group_end))
 
     def set_sources_dev(self, posm_dev_ptr: int, count: int):
         self._check(self._lib.nbody_set_sources_dev(self._h, posm_dev_ptr, count))

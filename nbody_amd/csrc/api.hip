@@ -57,6 +57,7 @@ void free_all(Sim *s)
     F(s->nodeA); F(s->nodeB); F(s->list_len); F(s->inter_dev); F(s->trav_tail); F(s->pot);
     F(s->tw_posm); F(s->tw_pot); F(s->ds_pot); F(s->let_boxes); F(s->let_counts);
     F(s->keybox); F(s->red_scratch); F(s->red_out); F(s->let_mask); F(s->let_seg); F(s->let_frontier);
+    F(s->let_reach); F(s->let_bsum); F(s->imp_roots); F(s->imp_desc);
     if (s->ev_ready) (void) hipEventDestroy(s->ev_ready);
     if (s->red_host) (void) hipHostFree(s->red_host);
     for (int k = 0; k < 3; ++k) { F(s->tw_v[k]); F(s->tw_vh[k]); F(s->tw_a[k]); F(s->ds_a[k]); }
@@ -857,6 +858,7 @@ int nbody_update(nbody_t *h)
     NB_ENTER(h);
     if (!s->spawned) return fail(s, NBODY_ERR_STATE, "update before spawn/set_state");
     if (s->pending_vel) return fail(s, NBODY_ERR_STATE, "nbody_finish_step not called");
+    s->imp_nroots = 0;   // copies of other trees belong to the step that imported them
     const bool timing = (s->p.flags & NBODY_FLAG_TIMING) != 0;
     const int slot = s->ev_head;
     if (timing && s->ev_pending == TIMING_RING) {
@@ -1331,6 +1333,138 @@ int nbody_traverse_from(nbody_t *h, nbody_t *sources, int32_t accumulate)
         NB_HIP(s, hipEventRecord(s->ev_ready, s->stream));
         NB_HIP(s, hipStreamWaitEvent(src->stream, s->ev_ready, 0));
     }
+    return NBODY_OK;
+}
+
+// Room for imported tree copies behind the own tree: node arrays from index 2 * cap on, particle
+// arrays from imp_part_base(s) on.  Growing re-allocates the four arrays and keeps their contents.
+static int imp_part_base(const Sim *s) { return (s->cap + 3) & ~3; }
+
+static int ensure_import_capacity(Sim *s, int nodes, int parts)
+{
+    if (nodes <= s->imp_node_cap && parts <= s->imp_part_cap) return NBODY_OK;
+    const int ncap = std::max(s->imp_node_cap, nodes + nodes / 4 + 1024);
+    const int pcap = std::max(s->imp_part_cap, parts + parts / 4 + 1024);
+    const size_t own_nodes = 2 * (size_t) s->cap, pb = (size_t) imp_part_base(s);
+    Float4 *nA = nullptr, *pm = nullptr;
+    NodeB *nB = nullptr;
+    float *pm2 = nullptr;
+    const size_t posm2_floats = 16 * ((pb + (size_t) pcap + 3) / 4);
+    NB_HIP(s, dalloc(&nA, own_nodes + ncap)); NB_HIP(s, dalloc(&nB, own_nodes + ncap));
+    NB_HIP(s, dalloc(&pm, pb + pcap)); NB_HIP(s, dalloc(&pm2, posm2_floats));
+    NB_HIP(s, hipMemsetAsync(pm2, 0, posm2_floats * 4, s->stream));
+    NB_HIP(s, hipMemcpyAsync(nA, s->nodeA, (own_nodes + s->imp_node_cap) * sizeof(Float4), hipMemcpyDeviceToDevice, s->stream));
+    NB_HIP(s, hipMemcpyAsync(nB, s->nodeB, (own_nodes + s->imp_node_cap) * sizeof(NodeB), hipMemcpyDeviceToDevice, s->stream));
+    const size_t old_parts = s->imp_part_cap ? pb + (size_t) s->imp_part_cap : (size_t) s->cap;
+    NB_HIP(s, hipMemcpyAsync(pm, s->posm, old_parts * sizeof(Float4), hipMemcpyDeviceToDevice, s->stream));
+    NB_HIP(s, hipMemcpyAsync(pm2, s->posm2, 16 * ((old_parts + 3) / 4) * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    NB_HIP(s, hipStreamSynchronize(s->stream));
+    NB_HIP(s, hipFree(s->nodeA)); NB_HIP(s, hipFree(s->nodeB)); NB_HIP(s, hipFree(s->posm)); NB_HIP(s, hipFree(s->posm2));
+    s->nodeA = nA; s->nodeB = nB; s->posm = pm; s->posm2 = pm2;
+    s->imp_node_cap = ncap; s->imp_part_cap = pcap;
+    return NBODY_OK;
+}
+
+int nbody_let_export_tree_dev(nbody_t *h, const float *frontiers_dev, int32_t ndomains, int32_t records_per_domain,
+                              int32_t skip_domain, void *out_dev, size_t capacity_bytes, int32_t *counts_dev)
+{
+    NB_ENTER(h);
+    NB_FLOAT_ONLY(s, "nbody_let_export_tree_dev");
+    if (!frontiers_dev || !out_dev || !counts_dev || ndomains < 1 || ndomains > LET_MAX_BOXES ||
+        records_per_domain < 1 || records_per_domain > LET_MAX_T || (capacity_bytes & 15))
+        return fail(s, NBODY_ERR_INVALID, "let_export_tree_dev: bad arguments");
+    if (!s->spawned || s->n < 1) return fail(s, NBODY_ERR_STATE, "let_export_tree before spawn/set_state");
+    if (!s->let_reach) {
+        NB_HIP(s, dalloc(&s->let_reach, 2 * (size_t) s->cap));
+        NB_HIP(s, dalloc(&s->let_bsum, (size_t) LET_MASK_DOMAINS * ((2 * (size_t) s->cap + 255) / 256) * 3));
+    }
+    for (int d0 = 0; d0 < ndomains; d0 += LET_MASK_DOMAINS) {
+        const int nd = std::min(LET_MASK_DOMAINS, ndomains - d0);
+        NB_HIP(s, launch_let_export_tree(s, frontiers_dev + (size_t) d0 * records_per_domain * LET_REC, nd,
+                                         records_per_domain, skip_domain - d0,
+                                         reinterpret_cast<unsigned char *>(out_dev) + (size_t) d0 * capacity_bytes,
+                                         capacity_bytes, reinterpret_cast<uint32_t *>(counts_dev) + 2 * d0));
+    }
+    return NBODY_OK;
+}
+
+int nbody_import_trees_dev(nbody_t *h, const void *recv_dev, int32_t ncopies, const size_t *byte_offset,
+                           const int32_t *node_count, const int32_t *record_count)
+{
+    NB_ENTER(h);
+    NB_FLOAT_ONLY(s, "nbody_import_trees_dev");
+    if (ncopies < 0 || ncopies > LET_MAX_BOXES || (ncopies > 0 && (!recv_dev || !byte_offset || !node_count || !record_count)))
+        return fail(s, NBODY_ERR_INVALID, "import_trees: bad arguments");
+    if (!s->spawned) return fail(s, NBODY_ERR_STATE, "import_trees before spawn/set_state");
+    if (!s->imp_roots) {
+        NB_HIP(s, dalloc(&s->imp_roots, (size_t) LET_MAX_BOXES));
+        NB_HIP(s, dalloc(&s->imp_desc, (size_t) 6 * LET_MAX_BOXES + 1));
+    }
+    long long nodes = 0, parts = 0;
+    for (int r = 0; r < ncopies; ++r) {
+        if (node_count[r] < 0 || record_count[r] < 0 || (byte_offset[r] & 15) || (node_count[r] == 0 && record_count[r] != 0))
+            return fail(s, NBODY_ERR_INVALID, "import_trees: bad copy descriptor");
+        nodes += node_count[r];
+        parts += record_count[r];
+    }
+    if (nodes + parts > 0x7fffffffLL || 2LL * s->cap + nodes > 0x7fffffffLL)
+        return fail(s, NBODY_ERR_CAPACITY, "import_trees: too many records");
+    int rc = ensure_import_capacity(s, (int) nodes, (int) parts);
+    if (rc) return rc;
+    // (pageable staging: a copy from it has read the words by the time the call returns)
+    std::vector<int32_t> words((size_t) 7 * LET_MAX_BOXES + 1);
+    int32_t *desc = words.data(), *prefix = desc + 5 * LET_MAX_BOXES, *roots = prefix + LET_MAX_BOXES + 1;
+    int nb = 2 * s->cap, pb = imp_part_base(s), items = 0, nroots = 0;
+    for (int r = 0; r < ncopies; ++r) {
+        desc[5 * r] = (int32_t) (byte_offset[r] / 16);
+        desc[5 * r + 1] = node_count[r]; desc[5 * r + 2] = record_count[r];
+        desc[5 * r + 3] = nb; desc[5 * r + 4] = pb;
+        prefix[r] = items;
+        if (node_count[r] > 0) roots[nroots++] = nb;
+        items += node_count[r] + record_count[r];
+        nb += node_count[r]; pb += record_count[r];
+    }
+    prefix[ncopies] = items;
+    s->imp_nroots = 0;
+    if (items > 0) {
+        NB_HIP(s, hipMemcpyAsync(s->imp_desc, desc, ((size_t) 6 * LET_MAX_BOXES + 1) * 4, hipMemcpyHostToDevice, s->stream));
+        NB_HIP(s, hipMemcpyAsync(s->imp_roots, roots, (size_t) std::max(nroots, 1) * 4, hipMemcpyHostToDevice, s->stream));
+        NB_HIP(s, launch_let_graft(s, ncopies, s->imp_desc, s->imp_desc + 5 * LET_MAX_BOXES, items,
+                                   reinterpret_cast<const unsigned char *>(recv_dev)));
+        s->imp_nroots = nroots;
+    }
+    return NBODY_OK;
+}
+
+int nbody_traverse_forest(nbody_t *h, int32_t what, int32_t group_begin, int32_t group_end)
+{
+    NB_ENTER(h);
+    NB_FLOAT_ONLY(s, "nbody_traverse_forest");
+    if (!s->spawned) return fail(s, NBODY_ERR_STATE, "traverse_forest before spawn/set_state");
+    const int ngroups = (s->n + s->group - 1) / s->group;
+    if (group_end < 0) { group_begin = 0; group_end = ngroups; }
+    if (what < 0 || what > 2 || group_begin < 0 || group_begin > group_end || group_end > ngroups)
+        return fail(s, NBODY_ERR_INVALID, "traverse_forest: bad arguments");
+    if (group_begin == group_end || (what == 2 && s->imp_nroots == 0)) return NBODY_OK;
+    const bool timed = (s->p.flags & NBODY_FLAG_TIMING) && s->ev_pending > 0;
+    const int slot = (s->ev_head + TIMING_RING - 1) % TIMING_RING;
+    const int k = timed ? s->tf_calls[slot] : 2;
+    if (k < 2) NB_HIP(s, hipEventRecord(s->ev[slot][EV_TF0_BEGIN + 2 * k], s->stream));
+    const int g0 = s->trav_g0, g1 = s->trav_g1;
+    s->trav_g0 = group_begin; s->trav_g1 = group_end;
+    hipError_t e = launch_traverse_forest(s, what);
+    s->trav_g0 = g0; s->trav_g1 = g1;
+    NB_HIP(s, e);
+    if (k < 2) NB_HIP(s, hipEventRecord(s->ev[slot][EV_TF0_END + 2 * k], s->stream));
+    if (timed) {
+        // list lengths of the groups of this call (a pass of the copies alone replaces a group's
+        // length by the copies' share, which is counted on top of the own tree's)
+        s->trav_g0 = group_begin; s->trav_g1 = group_end;
+        e = launch_count_interactions(s, (unsigned long long *) (s->inter_dev + slot), false, true);
+        s->trav_g0 = g0; s->trav_g1 = g1;
+        NB_HIP(s, e);
+    }
+    if (k < 2) s->tf_calls[slot] = k + 1;
     return NBODY_OK;
 }
 

@@ -5,16 +5,17 @@
 // The reference is single-GPU and has none of this; the scheme is the hybrid distributed
 // octree of the paper its README cites (Cazalbou et al., PASC'24, README.md:78).
 //
-// Streams.  S = the own handle's stream, R = the import handle's stream.  A step queues
-//   S: update (kick-drift, sort, build, centres of mass) -> frontier -> ALL-GATHER frontiers ->
-//      export -> ALL-TO-ALL counts -> copy of the counts to pinned memory -> [event C] ->
-//      own-tree traversal -> (waits for R's build) traversal of the imported tree -> kick
-//   host: waits for event C only (build + export, while the GPU already runs the own-tree
-//      traversal), sizes the record exchange from the counts
-//   R: (waits for event C) ALL-TO-ALL records -> unpack, sort, build, centres of mass
-// so the record exchange and the import build run under the own-tree traversal.
+// A step is queued on the own handle's stream:
+//   update (kick-drift, sort, build, centres of mass) -> frontier -> ALL-GATHER frontiers ->
+//   export of one pruned copy of the tree per remote domain -> ALL-TO-ALL of the copies' sizes ->
+//   copy of the sizes to pinned memory -> [event C] -> traversal of the first groups against
+//   the own tree alone (work that needs nothing from anybody, to cover the host's round trip) ->
+//   ALL-TO-ALL of the copies -> graft behind the own tree -> ONE traversal of the remaining
+//   groups over own and imported nodes -> imported nodes alone for the first groups -> kick.
+// The host waits for event C only, sizes the exchange from the counts and queues the rest.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -33,18 +34,17 @@ constexpr double DD_SLACK = 0.005;   // a cut may miss its target by this share 
 
 struct DD {
     Sim *own = nullptr;
-    nbody_t *remote = nullptr;       // import handle (created on first use, regrown on demand)
-    int remote_cap = 0;
     nbody_comm comm{};
     int T = LET_MAX_T;
     float *fr_send = nullptr, *fr_all = nullptr;
-    Float4 *exp_buf = nullptr;
-    int exp_cap = 0;
-    int32_t *cnt_dev = nullptr;      // [2W]: records per destination, records per origin
+    unsigned char *exp_buf = nullptr;   // [W] segments of exp_cap bytes: the copy for each domain
+    size_t exp_cap = 0;
+    int32_t *cnt_dev = nullptr;      // [4W]: (nodes, records) per destination, then per origin
     int32_t *cnt_host = nullptr;     // pinned copy
-    Float4 *recv_buf = nullptr;
+    unsigned char *recv_buf = nullptr;
     size_t recv_cap = 0;
     hipEvent_t ev_counts = nullptr;
+    int early_permille = 60;         // share of the groups walked before the copies arrive
     // re-balancing scratch
     uint64_t *q_dev = nullptr;       // query keys
     int32_t *lb_dev = nullptr;       // their positions in the sorted keys
@@ -92,53 +92,32 @@ nbody_t *H(Sim *s) { return reinterpret_cast<nbody_t *>(s); }
 
 int key_bits(const Sim *s) { return s->key_bytes == 4 ? 30 : 63; }
 
-int ensure_export_capacity(DD *d, int cap)
+int ensure_export_capacity(DD *d, size_t cap_bytes)
 {
-    if (cap <= d->exp_cap) return NBODY_OK;
+    cap_bytes = (cap_bytes + 255) / 256 * 256;
+    if (cap_bytes <= d->exp_cap) return NBODY_OK;
     if (d->exp_buf) DD_HIP(d, hipFree(d->exp_buf));
     d->exp_buf = nullptr;
     d->exp_cap = 0;
-    DD_HIP(d, hipMalloc((void **) &d->exp_buf, (size_t) d->comm.size * cap * sizeof(Float4)));
-    d->exp_cap = cap;
+    DD_HIP(d, hipMalloc((void **) &d->exp_buf, (size_t) d->comm.size * cap_bytes));
+    d->exp_cap = cap_bytes;
     return NBODY_OK;
 }
 
-// Import handle for `count` records: the own handle's parameters, smaller leaves (a far region
-// arrives as a handful of records that would otherwise share one leaf and never be
-// approximated), no validator, no timing.
-int ensure_remote(DD *d, size_t count)
-{
-    if (count <= (size_t) d->remote_cap) return NBODY_OK;
-    if (d->remote) nbody_destroy(d->remote);
-    d->remote = nullptr;
-    d->remote_cap = 0;
-    nbody_params p = d->own->p;
-    const size_t want = std::max<size_t>(count + count / 4 + 1024, (size_t) d->own->cap / 2);
-    p.num_points = (int32_t) std::min<size_t>(want, (size_t) (1 << 29) - 1);
-    // small leaves: the records were exported at the resolution the NEAREST body of this domain
-    // needs, most groups are farther away and accept whole cells of them, which a leaf of many
-    // codes would force them to sum one by one (8 x 2,097,152 sphere: lists of 333 sources per
-    // group with 4 codes per leaf, 895 with 8, 1296 with 32)
-    p.max_num_codes_per_leaf = std::min(4, p.max_num_codes_per_leaf);
-    p.num_steps_validator = 0;
-    p.flags = 0;
-    p.device_id = d->own->device;
-    if (nbody_create(&p, &d->remote) != NBODY_OK) return dfail(d, NBODY_ERR_HIP, "cannot create the import handle");
-    d->remote_cap = p.num_points;
-    return NBODY_OK;
-}
-
-int export_and_count(DD *d)
+// Exports the copies, exchanges their sizes and starts the sizes on their way to the host.
+int export_and_count(DD *d, bool have)
 {
     Sim *s = d->own;
     const int W = d->comm.size, me = d->comm.rank;
-    DD_NB(d, nbody_let_export_dev(H(s), d->fr_all, W, d->T, me, reinterpret_cast<float *>(d->exp_buf),
-                                  d->exp_cap, d->cnt_dev));
-    std::vector<size_t> four(W, sizeof(int32_t)), off(W);
-    for (int r = 0; r < W; ++r) off[r] = (size_t) r * sizeof(int32_t);
-    DD_COMM(d, d->comm.all_to_all(d->comm.ctx, d->cnt_dev, four.data(), off.data(), d->cnt_dev + W,
-                                  four.data(), off.data(), (void *) s->stream));
-    DD_HIP(d, hipMemcpyAsync(d->cnt_host, d->cnt_dev, (size_t) 2 * W * sizeof(int32_t),
+    if (have)
+        DD_NB(d, nbody_let_export_tree_dev(H(s), d->fr_all, W, d->T, me, d->exp_buf, d->exp_cap, d->cnt_dev));
+    else
+        DD_HIP(d, hipMemsetAsync(d->cnt_dev, 0, (size_t) 2 * W * sizeof(int32_t), s->stream));
+    std::vector<size_t> eight(W, 2 * sizeof(int32_t)), off(W);
+    for (int r = 0; r < W; ++r) off[r] = (size_t) r * 2 * sizeof(int32_t);
+    DD_COMM(d, d->comm.all_to_all(d->comm.ctx, d->cnt_dev, eight.data(), off.data(), d->cnt_dev + 2 * W,
+                                  eight.data(), off.data(), (void *) s->stream));
+    DD_HIP(d, hipMemcpyAsync(d->cnt_host, d->cnt_dev, (size_t) 4 * W * sizeof(int32_t),
                              hipMemcpyDeviceToHost, s->stream));
     DD_HIP(d, hipEventRecord(d->ev_counts, s->stream));
     return NBODY_OK;
@@ -251,13 +230,14 @@ int nbody_dd_create(nbody_t *own, const nbody_comm *comm, nbody_dd_t **out)
     if (!d) return NBODY_ERR_INVALID;
     d->own = s;
     d->comm = *comm;
+    if (const char *e = getenv("NBODY_DD_EARLY_PERMILLE")) d->early_permille = std::max(0, std::min(1000, atoi(e)));
     const int W = comm->size;
     Guard g(s->device);
     auto A = [&](void **p, size_t bytes) { return hipMalloc(p, std::max<size_t>(bytes, 16)); };
     hipError_t e = A((void **) &d->fr_send, (size_t) d->T * LET_REC * sizeof(float));
     if (e == hipSuccess) e = A((void **) &d->fr_all, (size_t) W * d->T * LET_REC * sizeof(float));
-    if (e == hipSuccess) e = A((void **) &d->cnt_dev, (size_t) 2 * W * sizeof(int32_t));
-    if (e == hipSuccess) e = hipHostMalloc((void **) &d->cnt_host, (size_t) 2 * W * sizeof(int32_t));
+    if (e == hipSuccess) e = A((void **) &d->cnt_dev, (size_t) 4 * W * sizeof(int32_t));
+    if (e == hipSuccess) e = hipHostMalloc((void **) &d->cnt_host, (size_t) 4 * W * sizeof(int32_t));
     if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_counts, hipEventDisableTiming);
     // one round of histograms per cut at most: (W - 1) x 4097 queries
     const size_t nq = (size_t) std::max(1, W - 1) * (DD_BINS + 1) + W + 1;
@@ -267,7 +247,7 @@ int nbody_dd_create(nbody_t *own, const nbody_comm *comm, nbody_dd_t **out)
     if (e == hipSuccess) e = A((void **) &d->hist_dev, d->hist_words * sizeof(uint32_t));
     if (e == hipSuccess) e = A((void **) &d->hist_all, d->hist_words * W * sizeof(uint32_t));
     if (e != hipSuccess) { nbody_dd_destroy(reinterpret_cast<nbody_dd_t *>(d)); return NBODY_ERR_HIP; }
-    if (W > 1 && ensure_export_capacity(d, std::max(4096, s->cap / 4)) != NBODY_OK) {
+    if (W > 1 && ensure_export_capacity(d, (size_t) std::max(4096, s->cap / 4) * 24) != NBODY_OK) {
         nbody_dd_destroy(reinterpret_cast<nbody_dd_t *>(d));
         return NBODY_ERR_HIP;
     }
@@ -288,7 +268,6 @@ void nbody_dd_destroy(nbody_dd_t *h)
     DD *d = reinterpret_cast<DD *>(h);
     Guard g(d->own->device);
     (void) hipStreamSynchronize(d->own->stream);
-    if (d->remote) nbody_destroy(d->remote);
     auto F = [](void *p) { if (p) (void) hipFree(p); };
     F(d->fr_send); F(d->fr_all); F(d->exp_buf); F(d->cnt_dev); F(d->recv_buf); F(d->q_dev); F(d->lb_dev);
     F(d->hist_dev); F(d->hist_all); F(d->mig_send); F(d->mig_recv);
@@ -310,7 +289,7 @@ int nbody_dd_step(nbody_dd_t *h)
     Guard g(s->device);
     const int W = d->comm.size, me = d->comm.rank;
     // A domain may be empty (more ranks than occupied key ranges): it still takes part in
-    // every collective, with an empty frontier and no records.
+    // every collective, with an empty frontier and no copies.
     const bool have = s->spawned && s->n > 0;
     if (have) DD_NB(d, nbody_update(H(s)));
     if (W == 1) {
@@ -319,6 +298,7 @@ int nbody_dd_step(nbody_dd_t *h)
             DD_NB(d, nbody_finish_step(H(s)));
         }
         d->stats.records_sent = d->stats.records_received = 0;
+        d->stats.nodes_sent = d->stats.nodes_received = 0;
         return NBODY_OK;
     }
     if (have) {
@@ -331,70 +311,65 @@ int nbody_dd_step(nbody_dd_t *h)
     }
     DD_COMM(d, d->comm.all_gather(d->comm.ctx, d->fr_send, d->fr_all, (size_t) d->T * LET_REC * sizeof(float),
                                   (void *) s->stream));
-    if (have) {
-        int rc = export_and_count(d);
-        if (rc) return rc;
-        // the own-tree traversal runs while the host sizes the exchange and the records travel
-        DD_NB(d, nbody_traverse_from(H(s), H(s), 0));
-    } else {
-        DD_HIP(d, hipMemsetAsync(d->cnt_dev, 0, (size_t) W * sizeof(int32_t), s->stream));
-        std::vector<size_t> four(W, sizeof(int32_t)), off(W);
-        for (int r = 0; r < W; ++r) off[r] = (size_t) r * sizeof(int32_t);
-        DD_COMM(d, d->comm.all_to_all(d->comm.ctx, d->cnt_dev, four.data(), off.data(), d->cnt_dev + W,
-                                      four.data(), off.data(), (void *) s->stream));
-        DD_HIP(d, hipMemcpyAsync(d->cnt_host, d->cnt_dev, (size_t) 2 * W * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream));
-        DD_HIP(d, hipEventRecord(d->ev_counts, s->stream));
-    }
-    DD_HIP(d, hipEventSynchronize(d->ev_counts));   // the step's one host wait
-    int need = 0;
-    for (int r = 0; r < W; ++r) need = std::max(need, d->cnt_host[r]);
-    if (need > d->exp_cap) {
-        // A destination needs more records than the buffer holds per destination (first steps, or
-        // the domains have changed).  The counts are the true ones either way and the peers
-        // have them already, so this is a local matter: grow the buffer and export again.
-        DD_HIP(d, hipStreamSynchronize(s->stream));
-        int rc = ensure_export_capacity(d, need + need / 4 + 1024);
-        if (rc) return rc;
-        DD_NB(d, nbody_let_export_dev(H(s), d->fr_all, W, d->T, me, reinterpret_cast<float *>(d->exp_buf),
-                                      d->exp_cap, d->cnt_dev));
-        DD_HIP(d, hipEventRecord(d->ev_counts, s->stream));
-    }
-    size_t total_recv = 0, total_send = 0;
-    std::vector<size_t> sb(W), so(W), rb(W), ro(W);
-    for (int r = 0; r < W; ++r) {
-        const size_t sc = r == me ? 0 : (size_t) d->cnt_host[r], rc = r == me ? 0 : (size_t) d->cnt_host[W + r];
-        sb[r] = sc * sizeof(Float4);
-        so[r] = (size_t) r * d->exp_cap * sizeof(Float4);
-        rb[r] = rc * sizeof(Float4);
-        ro[r] = total_recv * sizeof(Float4);
-        total_recv += rc;
-        total_send += sc;
-    }
-    d->stats.records_sent = (int64_t) total_send;
-    d->stats.records_received = (int64_t) total_recv;
-    d->stats.frontier_records = d->T;
-    d->stats.export_capacity = d->exp_cap;
-    int rc = ensure_remote(d, total_recv);
+    int rc = export_and_count(d, have);
     if (rc) return rc;
+    // While the sizes travel to the host and the copies between the GPUs, the first groups are
+    // walked against the own tree alone; they get the imported nodes in a pass of their own at
+    // the end.  The rest of the groups -- nearly all -- see own and imported nodes in ONE walk.
+    const int ngroups = have ? (s->n + s->group - 1) / s->group : 0;
+    const int early = have ? std::min(ngroups, (int) ((long long) ngroups * d->early_permille / 1000)) : 0;
+    if (early > 0) DD_NB(d, nbody_traverse_forest(H(s), 0, 0, early));
+    DD_HIP(d, hipEventSynchronize(d->ev_counts));   // the step's one host wait
+    size_t need = 0;
+    for (int r = 0; r < W; ++r)
+        need = std::max(need, (size_t) d->cnt_host[2 * r] * 32 + (size_t) d->cnt_host[2 * r + 1] * 16);
+    if (need > d->exp_cap) {
+        // A copy is larger than a segment of the buffer (first steps, or the domains have
+        // changed).  The sizes are the true ones either way and the peers have them already,
+        // so this is a local matter: grow the buffer and export again.
+        DD_HIP(d, hipStreamSynchronize(s->stream));
+        rc = ensure_export_capacity(d, need + need / 4 + 4096);
+        if (rc) return rc;
+        DD_NB(d, nbody_let_export_tree_dev(H(s), d->fr_all, W, d->T, me, d->exp_buf, d->exp_cap, d->cnt_dev));
+    }
+    size_t total_recv = 0;
+    int64_t rs = 0, rr = 0, ns = 0, nr = 0;
+    std::vector<size_t> sb(W), so(W), rb(W), ro(W), off;
+    std::vector<int32_t> cn, cr;
+    for (int r = 0; r < W; ++r) {
+        const bool other = r != me;
+        const int32_t snn = other ? d->cnt_host[2 * r] : 0, snr = other ? d->cnt_host[2 * r + 1] : 0;
+        const int32_t rnn = other ? d->cnt_host[2 * W + 2 * r] : 0, rnr = other ? d->cnt_host[2 * W + 2 * r + 1] : 0;
+        sb[r] = (size_t) snn * 32 + (size_t) snr * 16;
+        so[r] = (size_t) r * d->exp_cap;
+        rb[r] = (size_t) rnn * 32 + (size_t) rnr * 16;
+        ro[r] = total_recv;
+        if (other) { off.push_back(total_recv); cn.push_back(rnn); cr.push_back(rnr); }
+        total_recv += rb[r];
+        rs += snr; ns += snn; rr += rnr; nr += rnn;
+    }
+    d->stats.records_sent = rs; d->stats.records_received = rr;
+    d->stats.nodes_sent = ns; d->stats.nodes_received = nr;
+    d->stats.frontier_records = d->T;
+    d->stats.export_capacity = (int32_t) std::min<size_t>(d->exp_cap / 16, 0x7fffffff);
     if (total_recv > d->recv_cap) {
         if (d->recv_buf) DD_HIP(d, hipFree(d->recv_buf));   // implicit device synchronisation
         d->recv_buf = nullptr;
         d->recv_cap = 0;
-        const size_t cap = total_recv + total_recv / 4 + 1024;
-        DD_HIP(d, hipMalloc((void **) &d->recv_buf, cap * sizeof(Float4)));
+        const size_t cap = total_recv + total_recv / 4 + 4096;
+        DD_HIP(d, hipMalloc((void **) &d->recv_buf, cap));
         d->recv_cap = cap;
     }
-    Sim *rs = reinterpret_cast<Sim *>(d->remote);
-    hipStream_t R = rs ? rs->stream : s->stream;
-    DD_HIP(d, hipStreamWaitEvent(R, d->ev_counts, 0));   // the records are exported
-    DD_COMM(d, d->comm.all_to_all(d->comm.ctx, d->exp_buf, sb.data(), so.data(), d->recv_buf, rb.data(),
-                                  ro.data(), (void *) R));
-    if (rs) {
-        if (nbody_set_sources_dev(d->remote, reinterpret_cast<const float *>(d->recv_buf), (int32_t) total_recv) != NBODY_OK)
-            return dfail(d, NBODY_ERR_STATE, std::string("import build: ") + nbody_last_error(d->remote));
+    if (!d->recv_buf) {   // nothing to receive, ever: the collective still wants a pointer
+        DD_HIP(d, hipMalloc((void **) &d->recv_buf, 4096));
+        d->recv_cap = 4096;
     }
+    DD_COMM(d, d->comm.all_to_all(d->comm.ctx, d->exp_buf, sb.data(), so.data(), d->recv_buf, rb.data(),
+                                  ro.data(), (void *) s->stream));
     if (have) {
-        if (rs) DD_NB(d, nbody_traverse_from(H(s), d->remote, 1));
+        DD_NB(d, nbody_import_trees_dev(H(s), d->recv_buf, (int32_t) cn.size(), off.data(), cn.data(), cr.data()));
+        DD_NB(d, nbody_traverse_forest(H(s), 1, early, ngroups));       // own tree and copies, one walk
+        if (early > 0) DD_NB(d, nbody_traverse_forest(H(s), 2, 0, early));   // the copies alone, added
         DD_NB(d, nbody_finish_step(H(s)));
     }
     return NBODY_OK;

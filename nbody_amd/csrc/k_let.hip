@@ -290,6 +290,186 @@ __global__ __launch_bounds__(256) void k_let_emit(
         for (int k = 0; k < me.count; ++k) dst[k] = posm[me.first + k];
 }
 
+// ---------------------------------------------------------------------------
+// Export of the locally-essential tree AS A TREE.  What a remote domain d needs from this tree
+// is the set of REACHED nodes (no ancestor passes d's opening criterion): a pruned copy of the
+// tree whose leaves are this tree's reached leaves (with their particles) and the reached inner
+// nodes that pass (one (com, mass) record each, the node "as a particle").  The receiver can
+// hang that copy beside its own tree and walk both in one traversal -- no second sort, build
+// or centre-of-mass pass over the received records.
+//
+// Numbering.  Nodes are numbered breadth-first with the children of a node contiguous and the
+// child blocks of a level in the order of their parents.  The reached nodes are the root and the
+// children of the reached inner nodes that do not pass ("kept" nodes), so, in the same order,
+//   index of node o in the copy            R(o) = number of reached nodes before o
+//   index of the first child of a kept o   1 + S(o),  S(o) = sum of the child counts of the kept
+//                                                      nodes before o
+//   index of the first particle record     P(o) = particle records of the reached nodes before o
+// are three exclusive prefix sums in node order: k_let_tree_count (per workgroup and domain),
+// k_let_tree_scan (over the workgroups), k_let_tree_emit.  Per domain the output is one segment:
+// node records (32 bytes: com xyz, mass | size, first, count, meta -- the traversal's own two
+// records, `first` relative to the copy), then the particle records (16 bytes).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_let_reach(const Counts *counts,
+                                                   const int32_t *__restrict__ o_parent,
+                                                   const uint32_t *__restrict__ mask,
+                                                   uint32_t *__restrict__ reach)
+{
+    const int n_oct = counts->n_oct;
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < n_oct; o += gridDim.x * 256) {
+        uint32_t blocked = 0;
+        for (int a = o_parent[o]; a >= 0; a = o_parent[a]) blocked |= mask[a];
+        reach[o] = ~blocked;
+    }
+}
+
+// what node o contributes to domain `dom`'s copy: x = 1 | child count << 12 (kept nodes), y =
+// particle records
+__device__ __forceinline__ uint2 let_tree_contrib(int o, int n_oct, int dom,
+                                                  const uint32_t *__restrict__ reach,
+                                                  const uint32_t *__restrict__ mask,
+                                                  const NodeB *__restrict__ nodeB, NodeB *me,
+                                                  int *kind)
+{
+    *kind = 0;
+    if (o >= n_oct || !((reach[o] >> dom) & 1u)) return uint2{0u, 0u};
+    *me = nodeB[o];
+    if (me->meta & NODE_LEAF) { *kind = 1; return uint2{1u, (uint32_t) me->count}; }
+    if ((mask[o] >> dom) & 1u) { *kind = 2; return uint2{1u, 1u}; }
+    *kind = 3;
+    return uint2{1u | ((uint32_t) me->count << 12), 0u};
+}
+
+__global__ __launch_bounds__(256) void k_let_tree_count(const Counts *counts,
+                                                        const NodeB *__restrict__ nodeB,
+                                                        const uint32_t *__restrict__ mask,
+                                                        const uint32_t *__restrict__ reach,
+                                                        int skip, int nblk,
+                                                        uint32_t *__restrict__ bsum /* [dom][nblk][3] */)
+{
+    __shared__ uint32_t s_acc[3];
+    const int dom = blockIdx.y;
+    if (dom == skip) return;
+    const int n_oct = counts->n_oct;
+    if ((int) blockIdx.x * 256 >= n_oct) return;
+    if (threadIdx.x < 3) s_acc[threadIdx.x] = 0;
+    __syncthreads();
+    NodeB me;
+    int kind;
+    const uint2 c = let_tree_contrib(blockIdx.x * 256 + threadIdx.x, n_oct, dom, reach, mask, nodeB, &me, &kind);
+    const uint32_t a = wave_sum_u32(c.x & 0xfffu), k = wave_sum_u32(c.x >> 12), p = wave_sum_u32(c.y);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_acc[0], a); atomicAdd(&s_acc[1], k); atomicAdd(&s_acc[2], p); }
+    __syncthreads();
+    if (threadIdx.x < 3) bsum[((size_t) dom * nblk + blockIdx.x) * 3 + threadIdx.x] = s_acc[threadIdx.x];
+}
+
+// One workgroup per domain: exclusive scan of the per-workgroup sums in place, totals to
+// out_count[2 dom] (nodes) and [2 dom + 1] (particle records).
+__global__ __launch_bounds__(256) void k_let_tree_scan(const Counts *counts, int skip, int nblk,
+                                                       uint32_t *__restrict__ bsum,
+                                                       uint32_t *__restrict__ out_count)
+{
+    __shared__ uint32_t s_scan[5];
+    const int dom = blockIdx.x;
+    if (dom == skip) { if (threadIdx.x < 2) out_count[2 * dom + threadIdx.x] = 0; return; }
+    const int used = min(nblk, (counts->n_oct + 255) / 256);
+    uint32_t carry[3] = {0, 0, 0};
+    for (int base = 0; base < used; base += 256) {
+        const int b = base + (int) threadIdx.x;
+        uint32_t *q = bsum + ((size_t) dom * nblk + b) * 3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t v = b < used ? q[k] : 0u;
+            uint32_t tot;
+            const uint32_t ex = block_excl_scan_u32<4>(v, s_scan, &tot);
+            if (b < used) q[k] = carry[k] + ex;
+            carry[k] += tot;
+        }
+    }
+    if (threadIdx.x == 0) { out_count[2 * dom] = carry[0]; out_count[2 * dom + 1] = carry[2]; }
+}
+
+__global__ __launch_bounds__(256) void k_let_tree_emit(
+    const Counts *counts, const Float4 *__restrict__ nodeA, const NodeB *__restrict__ nodeB,
+    const Float4 *__restrict__ posm, const uint32_t *__restrict__ mask,
+    const uint32_t *__restrict__ reach, int skip, int nblk, const uint32_t *__restrict__ bsum,
+    const uint32_t *__restrict__ out_count, unsigned char *__restrict__ out, size_t cap_bytes)
+{
+    __shared__ uint32_t s_scan[5];
+    const int dom = blockIdx.y;
+    if (dom == skip) return;
+    const int n_oct = counts->n_oct;
+    if ((int) blockIdx.x * 256 >= n_oct) return;
+    const uint32_t tot_nodes = out_count[2 * dom], tot_parts = out_count[2 * dom + 1];
+    // over capacity: nothing is written, the caller sees the counts and comes back with more room
+    if ((size_t) tot_nodes * 32 + (size_t) tot_parts * 16 > cap_bytes) return;
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    NodeB me;
+    int kind;
+    const uint2 c = let_tree_contrib(o, n_oct, dom, reach, mask, nodeB, &me, &kind);
+    uint32_t t0, t1;
+    const uint32_t ex0 = block_excl_scan_u32<4>(c.x, s_scan, &t0);   // nodes | kept children << 12
+    const uint32_t ex1 = block_excl_scan_u32<4>(c.y, s_scan, &t1);
+    if (kind == 0) return;
+    const uint32_t *b3 = bsum + ((size_t) dom * nblk + blockIdx.x) * 3;
+    const uint32_t R = b3[0] + (ex0 & 0xfffu), S = b3[1] + (ex0 >> 12), P = b3[2] + ex1;
+    unsigned char *seg = out + (size_t) dom * cap_bytes;
+    Float4 *nA = reinterpret_cast<Float4 *>(seg + (size_t) R * 32);
+    NodeB *nB = reinterpret_cast<NodeB *>(seg + (size_t) R * 32 + 16);
+    Float4 *parts = reinterpret_cast<Float4 *>(seg + (size_t) tot_nodes * 32);
+    const Float4 A = nodeA[o];
+    *nA = A;
+    if (kind == 3) {   // kept: its children follow; a child is a leaf of the copy if it is a leaf or passes
+        uint32_t lm = me.meta & 0xffu;
+        for (int k = 0; k < me.count; ++k) lm |= ((mask[me.first + k] >> dom) & 1u) << k;
+        *nB = NodeB{me.size, (int32_t) (1u + S), me.count, lm};
+    } else if (kind == 2) {   // passes: the node as one particle
+        *nB = NodeB{me.size, (int32_t) P, 1, NODE_LEAF};
+        parts[P] = A;
+    } else {
+        *nB = NodeB{me.size, (int32_t) P, me.count, NODE_LEAF};
+        for (int k = 0; k < me.count; ++k) parts[P + k] = posm[me.first + k];
+    }
+}
+
+// Received copies -> the handle's own node and particle arrays, behind its own tree: copy r
+// (nn[r] node records, then np[r] particle records, at byte offset off[r] of `recv`) gets the
+// node indices [node_base[r], +nn[r]) and the particle indices [part_base[r], +np[r]); `first`
+// of every node is rebased accordingly.  desc = 5 ints per copy: off/16, nn, np, node_base, part_base;
+// item_prefix[r] = nodes + particles of the copies before r.
+__global__ __launch_bounds__(256) void k_let_graft(int ncopies, const int32_t *__restrict__ desc,
+                                                   const int32_t *__restrict__ item_prefix,
+                                                   const unsigned char *__restrict__ recv,
+                                                   Float4 *__restrict__ nodeA, NodeB *__restrict__ nodeB,
+                                                   Float4 *__restrict__ posm, float *__restrict__ posm2)
+{
+    const int total = item_prefix[ncopies];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        int lo = 0, hi = ncopies;   // largest r with item_prefix[r] <= i
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (item_prefix[mid] <= i) lo = mid; else hi = mid;
+        }
+        const int32_t *d = desc + 5 * lo;
+        const int j = i - item_prefix[lo];
+        const unsigned char *src = recv + (size_t) d[0] * 16;
+        if (j < d[1]) {
+            const Float4 A = *reinterpret_cast<const Float4 *>(src + (size_t) j * 32);
+            NodeB B = *reinterpret_cast<const NodeB *>(src + (size_t) j * 32 + 16);
+            B.first += (B.meta & NODE_LEAF) ? d[4] : d[3];
+            nodeA[d[3] + j] = A;
+            nodeB[d[3] + j] = B;
+        } else {
+            const int k = j - d[1];
+            const Float4 p = *reinterpret_cast<const Float4 *>(src + (size_t) d[1] * 32 + (size_t) k * 16);
+            const size_t q = (size_t) d[4] + k;
+            posm[q] = p;
+            float *r = posm2 + (q >> 1) * 8 + (q & 1);
+            r[0] = p.x; r[2] = p.y; r[4] = p.z; r[6] = p.w;
+        }
+    }
+}
+
 // (x,y,z,m) records -> the SoA arrays of a source-only handle.
 __global__ __launch_bounds__(256) void k_unpack_sources(int n, const Float4 *__restrict__ src,
                                                         float *__restrict__ x, float *__restrict__ y,
@@ -420,6 +600,36 @@ hipError_t launch_let_export(Sim *s, const float *frontiers_dev, int ndom, int T
                        s->nodeA, s->nodeB, frontiers_dev, ndom, T, skip, s->p.theta, s->let_mask);
     hipLaunchKernelGGL(k_let_emit, dim3(gx, ndom), dim3(256), 0, s->stream, s->counts, s->nodeA,
                        s->nodeB, s->o_parent, s->posm, s->let_mask, skip, out, cap, out_count);
+    return hipGetLastError();
+}
+
+// Pruned copies of the tree, one per remote domain (see k_let_tree_emit): out = [ndom] segments
+// of cap_bytes; out_count[2 d], [2 d + 1] = node and particle records of domain d's copy.
+hipError_t launch_let_export_tree(Sim *s, const float *frontiers_dev, int ndom, int T, int skip,
+                                  unsigned char *out, size_t cap_bytes, uint32_t *out_count)
+{
+    const int nblk = (2 * s->n + 255) / 256;
+    const size_t lds = ((size_t) ndom * T * 6 + (size_t) ndom * 6) * sizeof(float);
+    hipLaunchKernelGGL(k_let_mask, dim3(std::min(nblk, 2048)), dim3(256), lds, s->stream, s->counts,
+                       s->nodeA, s->nodeB, frontiers_dev, ndom, T, skip, s->p.theta, s->let_mask);
+    hipLaunchKernelGGL(k_let_reach, dim3(std::min(nblk, 2048)), dim3(256), 0, s->stream, s->counts,
+                       s->o_parent, s->let_mask, s->let_reach);
+    hipLaunchKernelGGL(k_let_tree_count, dim3(nblk, ndom), dim3(256), 0, s->stream, s->counts, s->nodeB,
+                       s->let_mask, s->let_reach, skip, nblk, s->let_bsum);
+    hipLaunchKernelGGL(k_let_tree_scan, dim3(ndom), dim3(256), 0, s->stream, s->counts, skip, nblk,
+                       s->let_bsum, out_count);
+    hipLaunchKernelGGL(k_let_tree_emit, dim3(nblk, ndom), dim3(256), 0, s->stream, s->counts, s->nodeA,
+                       s->nodeB, s->posm, s->let_mask, s->let_reach, skip, nblk, s->let_bsum, out_count, out,
+                       cap_bytes);
+    return hipGetLastError();
+}
+
+hipError_t launch_let_graft(Sim *s, int ncopies, const int32_t *desc_dev, const int32_t *prefix_dev,
+                            int total_items, const unsigned char *recv)
+{
+    if (total_items < 1) return hipSuccess;
+    hipLaunchKernelGGL(k_let_graft, dim3(std::min((total_items + 255) / 256, 4096)), dim3(256), 0, s->stream,
+                       ncopies, desc_dev, prefix_dev, recv, s->nodeA, s->nodeB, s->posm, s->posm2);
     return hipGetLastError();
 }
 

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
     const v8f *__restrict__ posm2, const Float4 *__restrict__ nodeA,
     const NodeB *__restrict__ nodeB, float theta, float eps2, float gravity, float domain,
     float dt, float keep, const TravTail *__restrict__ tail, int cur, int accumulate,
-    int stack_limit)
+    int stack_limit, const int32_t *__restrict__ roots, int nroots)
 {
     __shared__ WaveLds lds[TRAV_WAVES];
 
@@ -122,9 +122,23 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
 #endif
     int sp = 0, leaf_n = 0;
     {
-        const bool root_leaf = (nodeB[0].meta & NODE_LEAF) != 0u;
-        if (lane == 0) { L.stack[0] = 0; L.leaf[0] = 0; }
-        if (root_leaf) leaf_n = 1; else sp = 1;
+        if (!(accumulate & 4)) {   // (4: a pass over imported copies alone leaves the own root out)
+            const bool root_leaf = (nodeB[0].meta & NODE_LEAF) != 0u;
+            if (lane == 0) { L.stack[0] = 0; L.leaf[0] = 0; }
+            if (root_leaf) leaf_n = 1; else sp = 1;
+        }
+        // a forest: the roots of the pruned copies of other domains' trees that stand behind
+        // this tree's nodes in the same arrays (k_let_graft); nroots <= LET_MAX_BOXES < stack size
+        for (int r0 = 0; r0 < nroots; r0 += 64) {
+            const bool v = r0 + lane < nroots;
+            const int id = v ? roots[r0 + lane] : 0;
+            const bool lf = v && (nodeB[id].meta & NODE_LEAF) != 0u;
+            const unsigned long long lm = __ballot(lf), im = __ballot(v && !lf);
+            if (lf) L.leaf[leaf_n + mbcnt(lm)] = id;
+            else if (v) L.stack[sp + mbcnt(im)] = id;
+            leaf_n += (int) __popcll(lm);
+            sp += (int) __popcll(im);
+        }
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -674,8 +688,12 @@ __global__ __launch_bounds__(256) void k_direct(const Float4 *__restrict__ targe
 }
 
 // Bodies of `s` against the tree of `src` (the same handle for an ordinary step).
-static hipError_t traverse_impl(Sim *s, Sim *src, bool fuse_vel, int acc_flag, bool potential = false)
+// acc_flag: bit 0 = add to the accelerations, bit 2 = leave the own root out (forest only)
+static hipError_t traverse_impl(Sim *s, Sim *src, bool fuse_vel, int acc_flag, bool potential = false,
+                                bool forest = false)
 {
+    const int32_t *roots = forest ? src->imp_roots : nullptr;
+    const int nroots = forest ? src->imp_nroots : 0;
     const int ngroups = (s->n + s->group - 1) / s->group;
     const int g0 = s->trav_g1 < 0 ? 0 : s->trav_g0;
     const int g1 = s->trav_g1 < 0 ? ngroups : std::min(s->trav_g1, ngroups);
@@ -691,7 +709,7 @@ static hipError_t traverse_impl(Sim *s, Sim *src, bool fuse_vel, int acc_flag, b
     hipLaunchKernelGGL((k_traverse<GG, FV, (WO)>), dim3(grid), dim3(64 * TRAV_WAVES), 0, s->stream,    \
                        s->n, g0, g1, s->posm, src->posm, (const v8f *) src->posm2, src->nodeA,       \
                        src->nodeB, s->p.theta, eps2, s->p.gravity, s->p.domain_size, s->p.dt, keep,  \
-                       s->trav_tail, c, acc_flag, stack_limit)
+                       s->trav_tail, c, acc_flag, stack_limit, roots, nroots)
         const bool walk_only = (s->p.flags & NBODY_FLAG_DEBUG_WALK_ONLY) != 0;
         // test aid: a node stack with 32 usable entries makes unexpanded push-backs and
         // depth-first single-node rounds the common case
@@ -746,14 +764,22 @@ hipError_t launch_traverse_from(Sim *bodies, Sim *sources, bool accumulate)
     return traverse_impl(bodies, sources, false, accumulate ? 1 : 0);
 }
 
+// what = 0: the own tree alone; 1: own tree and the grafted copies of the other domains' trees
+// in one walk; 2: the copies alone, added.  Over the handle's traversal range.
+hipError_t launch_traverse_forest(Sim *s, int what)
+{
+    return traverse_impl(s, s, false, what == 2 ? 5 : 0, false, what != 0);
+}
+
 // all_groups_add: count every group and add to *out (after a nbody_traverse_from call);
 // otherwise *out = count over the traversal range of the step.
-hipError_t launch_count_interactions(Sim *s, unsigned long long *out, bool all_groups_add)
+// range_add: count the groups of the traversal range and add to *out.
+hipError_t launch_count_interactions(Sim *s, unsigned long long *out, bool all_groups_add, bool range_add)
 {
     const int ngroups = (s->n + s->group - 1) / s->group;
     const int g0 = (all_groups_add || s->trav_g1 < 0) ? 0 : s->trav_g0;
     const int g1 = (all_groups_add || s->trav_g1 < 0) ? ngroups : std::min(s->trav_g1, ngroups);
-    hipError_t e = all_groups_add ? hipSuccess : hipMemsetAsync(out, 0, sizeof(unsigned long long), s->stream);
+    hipError_t e = (all_groups_add || range_add) ? hipSuccess : hipMemsetAsync(out, 0, sizeof(unsigned long long), s->stream);
     if (e != hipSuccess) return e;
     if (g1 <= g0) return hipSuccess;
     const int grid = std::max(1, std::min(64, (g1 - g0 + 255) / 256));

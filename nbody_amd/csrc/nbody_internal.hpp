@@ -175,6 +175,14 @@ struct Sim {
     uint32_t *let_mask = nullptr;    // [2n] per node: domains whose opening criterion it passes
     int32_t *let_seg = nullptr;      // [LET_MAX_T + 2] first particles of the frontier nodes, count
     float *let_frontier = nullptr;   // [LET_MAX_T][LET_REC] frontier of nbody_let_frontier
+    uint32_t *let_reach = nullptr;   // [2n] per node: domains for which no ancestor passes
+    uint32_t *let_bsum = nullptr;    // [LET_MASK_DOMAINS][ceil(2n/256)][3] sums of the tree export
+    // pruned copies of other domains' trees grafted behind the own tree (nbody_import_trees_dev):
+    // nodeA/nodeB hold them from index 2*cap on, posm/posm2 from imp_part_base on
+    int imp_node_cap = 0, imp_part_cap = 0;
+    int32_t *imp_roots = nullptr;    // [LET_MAX_BOXES] device: node index of every copy's root
+    int32_t *imp_desc = nullptr;     // [6 * LET_MAX_BOXES + 1] device: copy descriptors + item prefix
+    int imp_nroots = 0;
     hipEvent_t ev_ready = nullptr;   // marks this handle's queued work for a waiting handle
 
     // caller-owned viewer buffers [pos.x, pos.y, pos.z, com.x, com.y, com.z, node_size] (nullable)
@@ -225,7 +233,8 @@ hipError_t launch_twin_kick_drift(int n, float dt, float domain, Float4 *posm, c
 hipError_t launch_vel_kick_raw(int n, float dt, float keep, const float *vhx, const float *vhy,
                                const float *vhz, const float *ax, const float *ay, const float *az,
                                float *vx, float *vy, float *vz, hipStream_t st);
-hipError_t launch_count_interactions(Sim *s, unsigned long long *out, bool all_groups_add = false);
+hipError_t launch_count_interactions(Sim *s, unsigned long long *out, bool all_groups_add = false,
+                                     bool range_add = false);
 hipError_t launch_traverse_from(Sim *bodies, Sim *sources, bool accumulate);
 hipError_t launch_potential(Sim *s);                        // -> s->pot
 hipError_t launch_export_view(Sim *s);                      // positions + node COM/size -> ext[]
@@ -234,6 +243,11 @@ hipError_t launch_frontier(Sim *s, float *records_dev, int T);
 hipError_t launch_let_export(Sim *s, const float *frontiers_dev, int ndom, int T, int skip,
                              Float4 *out, int cap, uint32_t *out_count);
 hipError_t launch_unpack_sources(Sim *s, const Float4 *src, int n);
+hipError_t launch_let_export_tree(Sim *s, const float *frontiers_dev, int ndom, int T, int skip,
+                                  unsigned char *out, size_t cap_bytes, uint32_t *out_count);
+hipError_t launch_let_graft(Sim *s, int ncopies, const int32_t *desc_dev, const int32_t *prefix_dev,
+                            int total_items, const unsigned char *recv);
+hipError_t launch_traverse_forest(Sim *s, int what);
 hipError_t launch_key_lower_bound(Sim *s, const uint64_t *queries_dev, int nq, int32_t *out_dev);
 hipError_t launch_pack_particles(Sim *s, float *out);              // 11 words per particle
 hipError_t launch_unpack_particles(Sim *s, const float *in, int n);
