@@ -342,7 +342,15 @@ def main():
                            morton_bits=args.morton_bits, device_id=local_rank, flags=flags)
         sim = nb.Simulation(params)
         stepper = parallel.DomainDecomposition(sim, f"cuda:{local_rank}", via_host=rehearse)
-        stepper.spawn(kind, n, p0, p1)      # own slice of the set, then key ranges + migration
+        inject = os.environ.get("NBODY_BENCH_FAIL_ALL_TO_ALL")   # test aid: "<rank>:<call index>"
+        if inject and int(inject.split(":")[0]) == rank:
+            stepper.comm.fail_all_to_all_at = int(inject.split(":")[1])
+        try:
+            stepper.spawn(kind, n, p0, p1)      # own slice of the set, then key ranges + migration
+        except Exception as e:   # noqa: BLE001
+            sys.stderr.write(f"bench.py rank {rank}: spawn failed: {e}\n")
+            sys.stderr.flush()
+            os._exit(3)
         n_here = stepper.stats()["n_local"]
     else:
         ic = nb.sample_ic(kind, n, 42, p0=p0, p1=p1)
@@ -358,11 +366,21 @@ def main():
             stepper = parallel.ShardedTraversal(parallel.GpuBackend(sim, f"cuda:{local_rank}"))
     U, M, n_oct = sim.tree_counts()
 
+    def die(where, exc):
+        # a failed collective or nbody_dd_* call: say what failed on this rank and leave at once,
+        # without waiting on the peers (the launcher ends them)
+        sys.stderr.write(f"bench.py rank {rank}: {where} failed: {exc}\n")
+        sys.stderr.flush()
+        os._exit(3)
+
     def one_step():
         if stepper is None:
             sim.update()
         else:
-            stepper.step()
+            try:
+                stepper.step()
+            except Exception as e:   # noqa: BLE001
+                die("step", e)
 
     def fence():
         if world > 1:
@@ -426,6 +444,29 @@ def main():
                              "relative_change": round((e_end - e_start) / abs(e_start), 6),
                              "note": "kinetic + tree potential (nbody_tree_energy)"}
     let_stats = stepper.stats() if let else None
+    per_rank = None
+    if world > 1:
+        # what every rank did, for reading a run whose aggregate looks wrong: per-rank step split
+        # and, for the domain decomposition, the phases of three more steps with an event between
+        # them (outside the timed region: each event costs a few microseconds of stream time)
+        mine = {"rank": rank, "particles": int(n_here), "build_ms": (tim["ms_integrate"] + tim["ms_sort"] + tim["ms_build"] + tim["ms_com"]) / max(args.steps, 1),
+                "traversal_ms": tim["ms_traverse"] / max(args.steps, 1), "interactions_per_step": tim["interactions"] / max(args.steps, 1)}
+        if let:
+            try:
+                stepper.set_phase_timing(True)
+                acc = None
+                for _ in range(3):
+                    stepper.step()
+                    ph = stepper.phases()
+                    acc = ph if acc is None else {k: acc[k] + v for k, v in ph.items()}
+                mine["phases"] = {k: v / 3 for k, v in acc.items()}
+                stepper.set_phase_timing(False)
+                mine["collective_calls"] = dict(stepper.comm.calls)
+            except Exception as e:   # noqa: BLE001
+                die("phase-timing steps", e)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered
     if let:
         stepper.close()
     sim.close()
@@ -589,7 +630,8 @@ def main():
                        "parallelism": "single" if world == 1 else
                        (f"{world} Morton-key ranges of equal particle count (all-gathered key "
                         "histograms), own tree per GPU, all-gather of top-of-tree nodes, "
-                        "locally-essential-tree exchange (all-to-all of records)" if let else
+                        "locally-essential-tree exchange (all-to-all of pruned tree copies, grafted "
+                        "behind the own tree and walked with it in one traversal)" if let else
                         f"replicated build, traversal sharded over {world} Morton ranges, "
                         "all-gather of accelerations"),
                        "tree": {"unique_codes": U, "leaves": M, "octree_nodes": n_oct}},
@@ -633,13 +675,37 @@ def main():
                                        f"{BUILD_BYTES_PER_PARTICLE[21]} with 63-bit keys); these kernels are "
                                        "dependency-latency-bound at this size, not bandwidth-bound"},
         }
+        if world > 1:
+            out["rccl_world"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                                 "collectives_on": coll_dev}
+            peak_i = 1024 * SUSTAINED_CLOCK_GHZ * 1e9 * 2
+            ranks = []
+            for pr in per_rank:
+                tf = FLOP_PER_INTERACTION * pr["interactions_per_step"] / (pr["traversal_ms"] * 1e-3) / 1e12 if pr["traversal_ms"] else 0.0
+                bg = build_bytes * pr["particles"] / (pr["build_ms"] * 1e-3) / 1e9 if pr["build_ms"] else 0.0
+                ranks.append({"rank": pr["rank"], "particles": pr["particles"], "build_ms": round(pr["build_ms"], 4),
+                              "traversal_ms": round(pr["traversal_ms"], 4),
+                              "interactions_per_step": round(pr["interactions_per_step"]),
+                              "roofline": {"achieved": round(tf, 2), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_TFLOPS, 4),
+                                           "frac_of_issue_bound_at_sustained_clock": round(pr["interactions_per_step"] / (pr["traversal_ms"] * 1e-3) / peak_i, 4) if pr["traversal_ms"] else None},
+                              "roofline_build": {"achieved": round(bg, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(bg / PEAK_HBM_GBS, 4)}})
+            out["per_rank"] = ranks
+            if let and all("phases" in pr for pr in per_rank):
+                keys = list(per_rank[0]["phases"].keys())
+                out["phases_over_ranks"] = {k: {"min": round(min(pr["phases"][k] for pr in per_rank), 4),
+                                                "mean": round(sum(pr["phases"][k] for pr in per_rank) / world, 4),
+                                                "max": round(max(pr["phases"][k] for pr in per_rank), 4)} for k in keys}
+                out["phases_note"] = ("mean of 3 steps after the timed region, one HIP event between phases: ms of GPU "
+                                      "stream time per phase (exchange includes waiting for the slowest peer), "
+                                      "ms_host_wait = host blocked on the sizes of the copies, bytes per rank and step")
+                out["collective_calls_rank0"] = per_rank[0].get("collective_calls")
         if let:
-            out["roofline"]["note"] += ("; rank 0's own-tree and imported-tree traversals "
-                                        "(both timed), interactions of rank 0")
+            out["roofline"]["note"] += ("; rank 0's traversal launches (own tree and imported copies in one "
+                                        "walk), interactions of rank 0")
             out["roofline"]["traffic"] = None
             st = let_stats
-            out["let_records_per_step"] = {"sent_rank0": st["records_sent"],
-                                           "received_rank0": st["records_received"]}
+            out["let_records_per_step"] = {"sent_rank0": st["records_sent"], "received_rank0": st["records_received"],
+                                           "nodes_sent_rank0": st["nodes_sent"], "nodes_received_rank0": st["nodes_received"]}
             out["domain_rank0"] = {"particles": st["n_local"], "first_key": st["splitters"][0],
                                    "end_key": st["splitters"][1]}
         if accuracy is not None:

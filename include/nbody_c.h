@@ -495,6 +495,26 @@ typedef struct nbody_dd_stats {
     int64_t nodes_received;     /* node records imported in the last step            */
 } nbody_dd_stats;
 int nbody_dd_get_stats(nbody_dd_t *dd, nbody_dd_stats *out, uint64_t *splitters);
+/* Where a step's time goes on this rank, for diagnosing a multi-GPU run: with phase timing on,
+ * nbody_dd_step() records a HIP event between its phases (a few microseconds of stream time
+ * each: leave it off in timed regions) and nbody_dd_get_phases() returns the last step's times
+ * in ms (it waits for that step).  GPU-side spans, in stream order: build (kick-drift, sort,
+ * tree, centres of mass), frontier (+ its all-gather), export (+ the all-to-all of the sizes),
+ * early_traversal (first groups, own tree only), sizing (the stream idles here while the host
+ * reads the sizes and queues the exchange), exchange (all-to-all of the copies: includes waiting
+ * for the slowest peer), graft, traversal (own tree + copies, and the copies' pass over the
+ * first groups, kick included).  ms_host_wait = host time blocked on the sizes; ms_host_total =
+ * host time inside nbody_dd_step. */
+typedef struct nbody_dd_phases {
+    float ms_build, ms_frontier, ms_export, ms_early_traversal, ms_sizing, ms_exchange, ms_graft,
+          ms_traversal, ms_total, ms_host_wait, ms_host_total;
+    int32_t pad;
+    int64_t bytes_frontier;     /* this rank's contribution to the frontier all-gather */
+    int64_t bytes_sent;         /* copies sent in the all-to-all (nodes 32 B, records 16 B) */
+    int64_t bytes_received;
+} nbody_dd_phases;
+int nbody_dd_set_phase_timing(nbody_dd_t *dd, int32_t on);
+int nbody_dd_get_phases(nbody_dd_t *dd, nbody_dd_phases *out);
 /* Pure host function behind nbody_dd_rebalance: cut positions from a global histogram.
  * hist[nbins] = particles per bin (bins in key order), parts domains, slack = tolerated
  * deviation of a cut from its target in particles.  For cut k = 1..parts-1 writes

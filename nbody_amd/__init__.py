@@ -81,6 +81,14 @@ class CComm(C.Structure):
                 ("all_gather", ALL_GATHER), ("all_to_all", ALL_TO_ALL)]
 
 
+class CDDPhases(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("ms_build", "ms_frontier", "ms_export", "ms_early_traversal",
+                                         "ms_sizing", "ms_exchange", "ms_graft", "ms_traversal", "ms_total",
+                                         "ms_host_wait", "ms_host_total")] + \
+               [("pad", C.c_int32), ("bytes_frontier", C.c_int64), ("bytes_sent", C.c_int64),
+                ("bytes_received", C.c_int64)]
+
+
 class CDDStats(C.Structure):
     _fields_ = [("n_local", C.c_int64), ("records_sent", C.c_int64), ("records_received", C.c_int64),
                 ("migrated_out", C.c_int64), ("frontier_records", C.c_int32),
@@ -114,6 +122,7 @@ EXPORTS = [
     "nbody_dd_rebalance", "nbody_dd_step", "nbody_dd_get_stats", "nbody_dd_choose_edges",
     "nbody_dd_refine_edge", "nbody_get_key_domain",
     "nbody_let_export_tree_dev", "nbody_import_trees_dev", "nbody_traverse_forest",
+    "nbody_dd_set_phase_timing", "nbody_dd_get_phases",
 ]
 
 _lib = None
@@ -208,6 +217,8 @@ def load_library() -> C.CDLL:
     lib.nbody_dd_rebalance.argtypes = [C.c_void_p]
     lib.nbody_dd_step.argtypes = [C.c_void_p]
     lib.nbody_dd_get_stats.argtypes = [C.c_void_p, C.POINTER(CDDStats), C.POINTER(C.c_uint64)]
+    lib.nbody_dd_set_phase_timing.argtypes = [C.c_void_p, C.c_int32]
+    lib.nbody_dd_get_phases.argtypes = [C.c_void_p, C.POINTER(CDDPhases)]
     lib.nbody_dd_choose_edges.argtypes = [C.POINTER(C.c_uint64), C.c_int32, C.c_int32, C.c_uint64,
                                           C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.nbody_dd_choose_edges.restype = None

@@ -1436,10 +1436,11 @@ int nbody_import_trees_dev(nbody_t *h, const void *recv_dev, int32_t ncopies, co
     return NBODY_OK;
 }
 
-int nbody_traverse_forest(nbody_t *h, int32_t what, int32_t group_begin, int32_t group_end)
+}  // extern "C"
+
+int nb::traverse_forest(Sim *s, int what, int group_begin, int group_end, bool kick)
 {
-    NB_ENTER(h);
-    NB_FLOAT_ONLY(s, "nbody_traverse_forest");
+    if (s->fp64) return fail(s, NBODY_ERR_STATE, "nbody_traverse_forest: float handles only");
     if (!s->spawned) return fail(s, NBODY_ERR_STATE, "traverse_forest before spawn/set_state");
     const int ngroups = (s->n + s->group - 1) / s->group;
     if (group_end < 0) { group_begin = 0; group_end = ngroups; }
@@ -1452,7 +1453,7 @@ int nbody_traverse_forest(nbody_t *h, int32_t what, int32_t group_begin, int32_t
     if (k < 2) NB_HIP(s, hipEventRecord(s->ev[slot][EV_TF0_BEGIN + 2 * k], s->stream));
     const int g0 = s->trav_g0, g1 = s->trav_g1;
     s->trav_g0 = group_begin; s->trav_g1 = group_end;
-    hipError_t e = launch_traverse_forest(s, what);
+    hipError_t e = launch_traverse_forest(s, what, kick);
     s->trav_g0 = g0; s->trav_g1 = g1;
     NB_HIP(s, e);
     if (k < 2) NB_HIP(s, hipEventRecord(s->ev[slot][EV_TF0_END + 2 * k], s->stream));
@@ -1466,6 +1467,14 @@ int nbody_traverse_forest(nbody_t *h, int32_t what, int32_t group_begin, int32_t
     }
     if (k < 2) s->tf_calls[slot] = k + 1;
     return NBODY_OK;
+}
+
+extern "C" {
+
+int nbody_traverse_forest(nbody_t *h, int32_t what, int32_t group_begin, int32_t group_end)
+{
+    NB_ENTER(h);
+    return nb::traverse_forest(s, what, group_begin, group_end, false);
 }
 
 // Energy of the current state with the potential taken from the tree (the reference only has

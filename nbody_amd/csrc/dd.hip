@@ -14,6 +14,7 @@
 //   groups over own and imported nodes -> imported nodes alone for the first groups -> kick.
 // The host waits for event C only, sizes the exchange from the counts and queues the rest.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -45,6 +46,11 @@ struct DD {
     size_t recv_cap = 0;
     hipEvent_t ev_counts = nullptr;
     int early_permille = 60;         // share of the groups walked before the copies arrive
+    // phase timing of the last step (nbody_dd_set_phase_timing): events on the stream + host clock
+    bool phase_timing = false, phases_valid = false;
+    hipEvent_t pev[9] = {};
+    double host_wait_ms = 0.0, host_total_ms = 0.0;
+    size_t bytes_sent = 0, bytes_received = 0;
     // re-balancing scratch
     uint64_t *q_dev = nullptr;       // query keys
     int32_t *lb_dev = nullptr;       // their positions in the sorted keys
@@ -273,6 +279,7 @@ void nbody_dd_destroy(nbody_dd_t *h)
     F(d->hist_dev); F(d->hist_all); F(d->mig_send); F(d->mig_recv);
     if (d->cnt_host) (void) hipHostFree(d->cnt_host);
     if (d->ev_counts) (void) hipEventDestroy(d->ev_counts);
+    for (hipEvent_t e : d->pev) if (e) (void) hipEventDestroy(e);
     delete d;
 }
 
@@ -291,7 +298,13 @@ int nbody_dd_step(nbody_dd_t *h)
     // A domain may be empty (more ranks than occupied key ranges): it still takes part in
     // every collective, with an empty frontier and no copies.
     const bool have = s->spawned && s->n > 0;
+    const bool pt = d->phase_timing;
+    const auto host_t0 = std::chrono::steady_clock::now();
+    auto mark = [&](int k) -> hipError_t { return pt ? hipEventRecord(d->pev[k], s->stream) : hipSuccess; };
+    d->phases_valid = false;
+    DD_HIP(d, mark(0));
     if (have) DD_NB(d, nbody_update(H(s)));
+    DD_HIP(d, mark(1));
     if (W == 1) {
         if (have) {
             DD_NB(d, nbody_traverse_from(H(s), H(s), 0));
@@ -311,15 +324,20 @@ int nbody_dd_step(nbody_dd_t *h)
     }
     DD_COMM(d, d->comm.all_gather(d->comm.ctx, d->fr_send, d->fr_all, (size_t) d->T * LET_REC * sizeof(float),
                                   (void *) s->stream));
+    DD_HIP(d, mark(2));
     int rc = export_and_count(d, have);
     if (rc) return rc;
+    DD_HIP(d, mark(3));
     // While the sizes travel to the host and the copies between the GPUs, the first groups are
     // walked against the own tree alone; they get the imported nodes in a pass of their own at
     // the end.  The rest of the groups -- nearly all -- see own and imported nodes in ONE walk.
     const int ngroups = have ? (s->n + s->group - 1) / s->group : 0;
     const int early = have ? std::min(ngroups, (int) ((long long) ngroups * d->early_permille / 1000)) : 0;
     if (early > 0) DD_NB(d, nbody_traverse_forest(H(s), 0, 0, early));
+    DD_HIP(d, mark(4));
+    const auto wait_t0 = std::chrono::steady_clock::now();
     DD_HIP(d, hipEventSynchronize(d->ev_counts));   // the step's one host wait
+    d->host_wait_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wait_t0).count();
     size_t need = 0;
     for (int r = 0; r < W; ++r)
         need = std::max(need, (size_t) d->cnt_host[2 * r] * 32 + (size_t) d->cnt_host[2 * r + 1] * 16);
@@ -364,14 +382,66 @@ int nbody_dd_step(nbody_dd_t *h)
         DD_HIP(d, hipMalloc((void **) &d->recv_buf, 4096));
         d->recv_cap = 4096;
     }
+    d->bytes_received = total_recv;
+    d->bytes_sent = 0;
+    for (int r = 0; r < W; ++r) d->bytes_sent += sb[r];
+    DD_HIP(d, mark(5));
     DD_COMM(d, d->comm.all_to_all(d->comm.ctx, d->exp_buf, sb.data(), so.data(), d->recv_buf, rb.data(),
                                   ro.data(), (void *) s->stream));
+    DD_HIP(d, mark(6));
     if (have) {
         DD_NB(d, nbody_import_trees_dev(H(s), d->recv_buf, (int32_t) cn.size(), off.data(), cn.data(), cr.data()));
-        DD_NB(d, nbody_traverse_forest(H(s), 1, early, ngroups));       // own tree and copies, one walk
-        if (early > 0) DD_NB(d, nbody_traverse_forest(H(s), 2, 0, early));   // the copies alone, added
-        DD_NB(d, nbody_finish_step(H(s)));
+        DD_HIP(d, mark(7));
+        // both passes are the last word on their groups' accelerations: the kick rides along
+        DD_NB(d, traverse_forest(s, 1, early, ngroups, true));          // own tree and copies, one walk
+        if (early > 0) {
+            if (s->imp_nroots > 0) DD_NB(d, traverse_forest(s, 2, 0, early, true));   // the copies alone, added
+            else {   // nobody sent anything: the first groups still want their kick
+                const int c = s->cur;
+                DD_HIP(d, launch_vel_kick_raw(std::min(early * s->group, s->n), s->p.dt, 1.0f - s->p.velocity_dampening,
+                                              s->vhx[c], s->vhy[c], s->vhz[c], s->ax, s->ay, s->az, s->vx[c], s->vy[c],
+                                              s->vz[c], s->stream));
+            }
+        }
+        s->pending_vel = false;
+    } else {
+        DD_HIP(d, mark(7));
     }
+    DD_HIP(d, mark(8));
+    d->host_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
+    d->phases_valid = pt;
+    return NBODY_OK;
+}
+
+int nbody_dd_set_phase_timing(nbody_dd_t *h, int32_t on)
+{
+    if (!h) return NBODY_ERR_INVALID;
+    DD *d = reinterpret_cast<DD *>(h);
+    Guard g(d->own->device);
+    if (on && !d->pev[0])
+        for (hipEvent_t &e : d->pev) DD_HIP(d, hipEventCreate(&e));
+    d->phase_timing = on != 0;
+    d->phases_valid = false;
+    return NBODY_OK;
+}
+
+int nbody_dd_get_phases(nbody_dd_t *h, nbody_dd_phases *out)
+{
+    if (!h || !out) return NBODY_ERR_INVALID;
+    DD *d = reinterpret_cast<DD *>(h);
+    if (!d->phases_valid) return dfail(d, NBODY_ERR_STATE, "no step has been timed (nbody_dd_set_phase_timing, then nbody_dd_step)");
+    Guard g(d->own->device);
+    DD_HIP(d, hipEventSynchronize(d->pev[8]));
+    float ms[8];
+    for (int k = 0; k < 8; ++k) DD_HIP(d, hipEventElapsedTime(&ms[k], d->pev[k], d->pev[k + 1]));
+    out->ms_build = ms[0]; out->ms_frontier = ms[1]; out->ms_export = ms[2]; out->ms_early_traversal = ms[3];
+    out->ms_sizing = ms[4]; out->ms_exchange = ms[5]; out->ms_graft = ms[6]; out->ms_traversal = ms[7];
+    DD_HIP(d, hipEventElapsedTime(&out->ms_total, d->pev[0], d->pev[8]));
+    out->ms_host_wait = (float) d->host_wait_ms;
+    out->ms_host_total = (float) d->host_total_ms;
+    out->bytes_frontier = (int64_t) d->T * LET_REC * sizeof(float);
+    out->bytes_sent = (int64_t) d->bytes_sent;
+    out->bytes_received = (int64_t) d->bytes_received;
     return NBODY_OK;
 }
 

@@ -419,8 +419,11 @@ __global__ __launch_bounds__(256) void k_let_tree_emit(
     Float4 *parts = reinterpret_cast<Float4 *>(seg + (size_t) tot_nodes * 32);
     const Float4 A = nodeA[o];
     *nA = A;
-    if (kind == 3) {   // kept: its children follow; a child is a leaf of the copy if it is a leaf or passes
-        uint32_t lm = me.meta & 0xffu;
+    if (kind == 3) {
+        // kept: its children follow.  Marked as "leaf child" (taken without a test) are the
+        // children that pass for the whole domain; real leaves are left to the receiver's own
+        // test, so that its far groups take them as one source instead of particle by particle.
+        uint32_t lm = 0;
         for (int k = 0; k < me.count; ++k) lm |= ((mask[me.first + k] >> dom) & 1u) << k;
         *nB = NodeB{me.size, (int32_t) (1u + S), me.count, lm};
     } else if (kind == 2) {   // passes: the node as one particle

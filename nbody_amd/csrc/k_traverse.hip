@@ -129,15 +129,11 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
         }
         // a forest: the roots of the pruned copies of other domains' trees that stand behind
         // this tree's nodes in the same arrays (k_let_graft); nroots <= LET_MAX_BOXES < stack size
+        // (every root is a candidate, leaves included: see the opening of leaves below)
         for (int r0 = 0; r0 < nroots; r0 += 64) {
-            const bool v = r0 + lane < nroots;
-            const int id = v ? roots[r0 + lane] : 0;
-            const bool lf = v && (nodeB[id].meta & NODE_LEAF) != 0u;
-            const unsigned long long lm = __ballot(lf), im = __ballot(v && !lf);
-            if (lf) L.leaf[leaf_n + mbcnt(lm)] = id;
-            else if (v) L.stack[sp + mbcnt(im)] = id;
-            leaf_n += (int) __popcll(lm);
-            sp += (int) __popcll(im);
+            const int k = min(64, nroots - r0);
+            if (lane < k) L.stack[sp + lane] = roots[r0 + lane];
+            sp += k;
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -489,8 +485,13 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
         total += (uint32_t) na;
 
         // opened nodes -> inner children to the node stack, leaf children to the leaf stack
-        const uint32_t nc = open ? (uint32_t) B.count : 0u;
-        const uint32_t lmask = open ? (B.meta & 0xffu) : 0u;
+        // A leaf among the candidates (only imported copies have them there: their senders
+        // mark as "leaf child" only what every group of this domain accepts, so that a real leaf
+        // is tested like any node and taken as one (com, mass) source by the groups far from
+        // it) opens into itself: its id goes to the leaf stack, as its one leaf child.
+        const bool self_leaf = open && (B.meta & NODE_LEAF) != 0u;
+        const uint32_t nc = open ? (self_leaf ? 1u : (uint32_t) B.count) : 0u;
+        const uint32_t lmask = open ? (self_leaf ? 1u : (B.meta & 0xffu)) : 0u;
         const uint32_t cl = (uint32_t) __popc(lmask);
         const uint32_t packed = (nc - cl) | (cl << 16);
         const uint32_t inc = wave_incl_scan_u32(packed);
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
         if (fits) {
             int di = sp + n_back + (int) (exc & 0xffffu), dl = leaf_n + (int) (exc >> 16);
             for (uint32_t c = 0; c < nc; ++c) {
-                const int child = B.first + (int) c;
+                const int child = self_leaf ? node : B.first + (int) c;
                 if ((lmask >> c) & 1u) L.leaf[dl++] = child; else L.stack[di++] = child;
             }
         }
@@ -766,9 +767,9 @@ hipError_t launch_traverse_from(Sim *bodies, Sim *sources, bool accumulate)
 
 // what = 0: the own tree alone; 1: own tree and the grafted copies of the other domains' trees
 // in one walk; 2: the copies alone, added.  Over the handle's traversal range.
-hipError_t launch_traverse_forest(Sim *s, int what)
+hipError_t launch_traverse_forest(Sim *s, int what, bool kick)
 {
-    return traverse_impl(s, s, false, what == 2 ? 5 : 0, false, what != 0);
+    return traverse_impl(s, s, kick, what == 2 ? 5 : 0, false, what != 0);
 }
 
 // all_groups_add: count every group and add to *out (after a nbody_traverse_from call);

@@ -247,7 +247,11 @@ hipError_t launch_let_export_tree(Sim *s, const float *frontiers_dev, int ndom, 
                                   unsigned char *out, size_t cap_bytes, uint32_t *out_count);
 hipError_t launch_let_graft(Sim *s, int ncopies, const int32_t *desc_dev, const int32_t *prefix_dev,
                             int total_items, const unsigned char *recv);
-hipError_t launch_traverse_forest(Sim *s, int what);
+hipError_t launch_traverse_forest(Sim *s, int what, bool kick);
+// nbody_traverse_forest with the velocity kick of the groups it covers fused into the launch
+// (kick = true: the caller sees to it that every group is kicked exactly once and clears
+// pending_vel itself).
+int traverse_forest(Sim *s, int what, int group_begin, int group_end, bool kick);
 hipError_t launch_key_lower_bound(Sim *s, const uint64_t *queries_dev, int nq, int32_t *out_dev);
 hipError_t launch_pack_particles(Sim *s, float *out);              // 11 words per particle
 hipError_t launch_unpack_particles(Sim *s, const float *in, int n);

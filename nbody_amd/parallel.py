@@ -277,6 +277,11 @@ class TorchComm:
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.error = None
+        # fault injection for tests of the error path: the all_to_all call with this index
+        # (0-based) reports failure instead of communicating; None = never
+        self.fail_all_to_all_at = None
+        self.calls = {"all_gather": 0, "all_to_all": 0}
+        self.bytes = {"all_gather": 0, "all_to_all_sent": 0, "all_to_all_received": 0}
         self._ag = nb.CComm.ALL_GATHER(self._all_gather)
         self._a2a = nb.CComm.ALL_TO_ALL(self._all_to_all)
         self.c = nb.CComm(self.rank, self.size, None, self._ag, self._a2a)
@@ -291,6 +296,8 @@ class TorchComm:
 
     def _all_gather(self, ctx, send, recv, nbytes, stream):
         try:
+            self.calls["all_gather"] += 1
+            self.bytes["all_gather"] += int(nbytes)
             with self._stream(stream):
                 s, r = self._t(send, nbytes), self._t(recv, nbytes * self.size)
                 if self.via_host:
@@ -307,8 +314,14 @@ class TorchComm:
     def _all_to_all(self, ctx, send, sbytes, soff, recv, rbytes, roff, stream):
         try:
             W = self.size
+            k = self.calls["all_to_all"]
+            self.calls["all_to_all"] = k + 1
+            if self.fail_all_to_all_at is not None and k == self.fail_all_to_all_at:
+                raise RuntimeError(f"injected failure of all_to_all call {k} on rank {self.rank}")
             sb, so = [int(sbytes[r]) for r in range(W)], [int(soff[r]) for r in range(W)]
             rb, ro = [int(rbytes[r]) for r in range(W)], [int(roff[r]) for r in range(W)]
+            self.bytes["all_to_all_sent"] += sum(sb)
+            self.bytes["all_to_all_received"] += sum(rb)
             with self._stream(stream):
                 sbuf = self._t(send, max((o + b for o, b in zip(so, sb)), default=0))
                 rbuf = self._t(recv, max((o + b for o, b in zip(ro, rb)), default=0))
@@ -373,6 +386,15 @@ class DomainDecomposition:
         out = {k: getattr(st, k) for k, _ in self._nb.CDDStats._fields_}
         out["splitters"] = [int(v) for v in sp]
         return out
+
+    def set_phase_timing(self, on=True):
+        self._check(self._lib.nbody_dd_set_phase_timing(self._h, 1 if on else 0))
+
+    def phases(self):
+        """Times (ms) and bytes of the last step's phases on this rank (set_phase_timing first)."""
+        ph = self._nb.CDDPhases()
+        self._check(self._lib.nbody_dd_get_phases(self._h, self._C.byref(ph)))
+        return {k: getattr(ph, k) for k, _ in self._nb.CDDPhases._fields_ if k != "pad"}
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

@@ -122,11 +122,12 @@ def test_exported_copy_is_a_breadth_first_tree_over_the_flat_export(kind, bits, 
             lv = np.flatnonzero(leaf)
             assert np.array_equal(t["first"][lv], np.concatenate([[0], np.cumsum(t["count"][lv])[:-1]]))
             assert t["count"][lv].sum() == npart
-            # the child-leaf mask of an inner node says which of its children are leaves
+            # the child mask of an inner node marks children that need no test: single-record
+            # leaves (nodes that pass for the whole domain); never an inner child
             for o in inner:
                 kids = np.arange(t["first"][o], t["first"][o] + t["count"][o])
-                want = sum(1 << k for k, c in enumerate(kids) if leaf[c])
-                assert int(t["meta"][o]) == want
+                may = sum(1 << k for k, c in enumerate(kids) if leaf[c] and t["count"][c] == 1)
+                assert int(t["meta"][o]) & ~may == 0
                 # a node's mass is its children's (float32 sums in the sender's order)
                 assert np.isclose(t["com"][kids, 3].sum(), t["com"][o, 3], rtol=1e-5)
                 assert np.all(t["size"][kids] <= t["size"][o] * 0.5)
@@ -141,15 +142,16 @@ def _f32_fma(a, b, c):
 
 def walk_copy(t, bx, by, bz, theta, domain):
     """Sources (indices into t['parts'] and node ids accepted as (com, mass)) a group of bodies
-    takes from a copy: the traversal's rule -- a leaf is taken whole, an inner node is accepted
-    iff size^2 / min_b |x_b - com|^2 < theta^2 (float32, the kernel's operation order)."""
+    takes from a copy: a child its parent marks is taken whole without a test; any other node,
+    leaf or not, is accepted as one source iff size^2 / min_b |x_b - com|^2 < theta^2 (float32,
+    the kernel's operation order), else a leaf is taken whole and an inner node opened."""
     th2 = np.float32(theta) * np.float32(theta)
     leaf = (t["meta"] & LEAF) != 0
     parts, coms = [], []
-    stack = [0]
+    stack = [(0, False)]
     while stack:
-        o = stack.pop()
-        if leaf[o]:
+        o, untested = stack.pop()
+        if untested:
             parts.extend(range(t["first"][o], t["first"][o] + t["count"][o]))
             continue
         dx, dy, dz = bx - t["com"][o, 0], by - t["com"][o, 1], bz - t["com"][o, 2]
@@ -158,8 +160,10 @@ def walk_copy(t, bx, by, bz, theta, domain):
         with np.errstate(divide="ignore"):
             if (t["size"][o] * t["size"][o]) / dmin < th2:
                 coms.append(o)
+            elif leaf[o]:
+                parts.extend(range(t["first"][o], t["first"][o] + t["count"][o]))
             else:
-                stack.extend(range(t["first"][o], t["first"][o] + t["count"][o]))
+                stack.extend((t["first"][o] + k, bool((int(t["meta"][o]) >> k) & 1)) for k in range(t["count"][o]))
     return parts, coms
 
 

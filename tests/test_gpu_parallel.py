@@ -221,6 +221,7 @@ def test_native_domain_decomposition_processes_share_the_gpu(tmp_path, world, n,
     res = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     split = res[0]["split"]
     assert int(split[0]) == 0 and int(split[-1]) == 1 << (3 * bits)
+    errs = {}
     for tag in ("1", ""):
         full = {k: np.full(n, np.nan, np.float32) for k in ("x", "y", "z", "m", "ax", "ay", "az")}
         for r, d in enumerate(res):
@@ -232,6 +233,7 @@ def test_native_domain_decomposition_processes_share_the_gpu(tmp_path, world, n,
         ref = O.direct_f64(full["x"], full["y"], full["z"], full["m"], 0.01, 1.0)
         mean, mx = O.acc_error(full["ax"], full["ay"], full["az"], *ref)
         # (inside a uniform sphere the forces largely cancel: the single-tree code is at 3e-3 here)
+        errs[tag] = (mean, mx)
         assert mean < 1e-2 and mx < 0.3, (tag, mean, mx)
     for r, d in enumerate(res):
         assert np.array_equal(d["split"], split)
@@ -247,10 +249,18 @@ def test_native_domain_decomposition_processes_share_the_gpu(tmp_path, world, n,
         one.set_state(ic["x"], ic["y"], ic["z"], ic["m"])
         one.update()
         s1 = one.get_state()
-    full1 = {k: np.empty(n, np.float32) for k in ("x", "ax")}
+    full1 = {k: np.empty(n, np.float32) for k in ("x", "y", "z", "m", "ax", "ay", "az")}
     for d in res:
         for k in full1:
             full1[k][d["gid1"]] = d[k + "1"]
     assert np.array_equal(full1["x"][s1["id"]], s1["x"])
-    scale = np.abs(s1["ax"]).max()
-    assert np.max(np.abs(full1["ax"][s1["id"]] - s1["ax"])) < 2e-2 * scale
+    # every component, per body, against the single tree: a lost or doubled copy of a
+    # neighbour's nodes would show here at once
+    scale = np.sqrt(s1["ax"].astype(np.float64) ** 2 + s1["ay"] ** 2 + s1["az"] ** 2).max()
+    for k in ("ax", "ay", "az"):
+        assert np.max(np.abs(full1[k][s1["id"]] - s1[k])) < 1e-2 * scale, k
+    # and the error against the direct sum is the single tree's, not worse
+    ref = O.direct_f64(s1["x"], s1["y"], s1["z"], s1["m"], 0.01, 1.0)
+    mean_one, max_one = O.acc_error(s1["ax"], s1["ay"], s1["az"], *ref)
+    assert errs["1"][0] < 1.5 * mean_one, (errs, mean_one)
+    assert errs["1"][1] < 3 * max_one + 5e-2, (errs, max_one)
