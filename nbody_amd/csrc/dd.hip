@@ -8,11 +8,14 @@
 // A step is queued on the own handle's stream:
 //   update (kick-drift, sort, build, centres of mass) -> frontier -> ALL-GATHER frontiers ->
 //   export of one pruned copy of the tree per remote domain -> ALL-TO-ALL of the copies' sizes ->
-//   copy of the sizes to pinned memory -> [event C] -> traversal of the first groups against
-//   the own tree alone (work that needs nothing from anybody, to cover the host's round trip) ->
-//   ALL-TO-ALL of the copies -> graft behind the own tree -> ONE traversal of the remaining
-//   groups over own and imported nodes -> imported nodes alone for the first groups -> kick.
+//   copy of the sizes to pinned memory -> [event C] -> ALL-TO-ALL of the copies -> graft behind
+//   the own tree -> ONE traversal over own and imported nodes, velocity kick included.
 // The host waits for event C only, sizes the exchange from the counts and queues the rest.
+// NBODY_DD_EARLY_PERMILLE=k (default 0) walks the first k/1000 of the groups against the own
+// tree alone before the host wait, to give the GPU work while the sizes and the copies travel,
+// and adds the imported nodes to those groups in a pass of their own at the end; on one GPU
+// playing 8 ranks of 2,097,152 particles that costs 0.55 ms per step at k = 60 (two more
+// launches, each with its own tail), more than the idle time it can cover, so it is off.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -45,7 +48,7 @@ struct DD {
     unsigned char *recv_buf = nullptr;
     size_t recv_cap = 0;
     hipEvent_t ev_counts = nullptr;
-    int early_permille = 60;         // share of the groups walked before the copies arrive
+    int early_permille = 0;          // share of the groups walked before the copies arrive (NBODY_DD_EARLY_PERMILLE)
     // phase timing of the last step (nbody_dd_set_phase_timing): events on the stream + host clock
     bool phase_timing = false, phases_valid = false;
     hipEvent_t pev[9] = {};
