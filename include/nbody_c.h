@@ -169,7 +169,11 @@ int nbody_get_num_octree_nodes(nbody_t *sim, int32_t *out);
  * src/cuda/validator.cu:322-353): CSV `sys_energy,sys_energy_ap,avg_acc_err`. */
 int nbody_write_validation_history(nbody_t *sim, const char *csv_path);
 /* The same records as arrays (up to `capacity`); *count = records available.  With
- * num_steps_validator > 0 every nbody_update() appends one record (and synchronises):
+ * num_steps_validator > 0 every nbody_update() appends one record (and synchronises).  The
+ * record is taken at the END of the update: record i describes the state after step i + 1.
+ * The reference takes it at the START of update() (src/cuda/simulation.cu:227-229), so its
+ * row i is the state after step i and its row 0 compares two all-zero accelerations; the
+ * rows here are the reference's rows shifted by one step.  A record holds the
  * total energy of the tree run, total energy of an all-pairs twin run advanced by direct
  * sums (Validator<T>, src/cuda/validator.cu:238-320), and the step-local mean relative
  * acceleration error of the tree forces against a direct sum at the same positions
@@ -324,7 +328,12 @@ int nbody_direct_energy_dev(const float *posm, const float *vx, const float *vy,
  * does not synchronise, and is limited to n <= 4,194,304 (NBODY_ERR_CAPACITY beyond that: use
  * nbody_direct_energy_dev).  The stream's device must be current.  All calls on one GPU share
  * that GPU's array: calls that overlap in time on one GPU (different streams, different
- * threads) race; calls on one stream, or otherwise ordered, are safe. */
+ * threads) race; calls on one stream, or otherwise ordered, are safe.
+ * Under stream capture: the address of the array is looked up once per device
+ * (hipGetSymbolAddress, not a stream operation and not legal inside a capture); nbody_create
+ * does that for its handle's device, and so does the first call of this function on a device.
+ * A capture may therefore contain calls of this function if a handle has been created on the
+ * device, or one call has been made there, BEFORE the capture began. */
 int nbody_direct_energy_dev_noalloc(const float *posm, const float *vx, const float *vy,
                                     const float *vz, int32_t n, float softening_factor,
                                     float gravity, double *out_dev, void *stream);

@@ -787,6 +787,7 @@ int nbody_create(const nbody_params *params, nbody_t **out)
         delete s;
         return rc;
     }
+    noalloc_prepare_current_device();
     *out = reinterpret_cast<nbody_t *>(s);
     return NBODY_OK;
 }

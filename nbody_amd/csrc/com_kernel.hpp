@@ -32,6 +32,15 @@
 #include "dev_utils.hpp"
 #include "nbody_internal.hpp"
 
+// The hand-off of the climb (write-through stores, s_waitcnt vmcnt(0), relaxed agent-scope
+// counter add, agent-scope loads) is written for the cache hierarchy of gfx942 / gfx950, where
+// agent-scope atomic stores and loads go past the XCD's L2.  It is not a statement in the HIP
+// memory model: on another target the counter add would have to be acquire-release
+// (__ATOMIC_ACQ_REL) and the sums ordinary stores and loads.  Refuse to build elsewhere.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "com_kernel.hpp: the centre-of-mass hand-off is written for gfx942/gfx950 (see the note above)"
+#endif
+
 namespace nb {
 
 // most particles under a local root: what one wave stages in LDS (8 KB)

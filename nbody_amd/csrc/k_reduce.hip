@@ -249,6 +249,21 @@ hipError_t scratch_for_current_device(unsigned char **out)
     return hipSuccess;
 }
 
+}  // namespace
+
+// Looks the scratch address of the current device up ahead of time (nbody_create does, for its
+// device), so that no later nbody_direct_energy_dev_noalloc call on that device has anything
+// left to resolve -- a call under stream capture must not.
+namespace nb {
+void noalloc_prepare_current_device()
+{
+    unsigned char *p = nullptr;
+    (void) scratch_for_current_device(&p);
+}
+}  // namespace nb
+
+namespace {
+
 bool energy_args_ok(const float *posm, const float *vx, const float *vy, const float *vz, int32_t n,
                     float softening_factor, double *out_dev)
 {

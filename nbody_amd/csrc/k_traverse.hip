@@ -146,13 +146,18 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
     const float th2 = theta * theta;
     const float dinit = domain * domain * 3.0f;
 
-    // Potential mode: 1/sqrt(s) of a source pair, with a source at zero distance (s == eps^2:
-    // the body itself, which its own leaf always delivers) contributing nothing.  Subtracting
-    // m_i / eps afterwards instead would leave the float sum with the rounding of a term that
-    // can be 10^3 times all the others together (a heavy body, a small softening).
-    auto pot_rsq = [&](const v2f s) -> v2f {
-        return v2f{s.x == eps2 ? 0.f : __builtin_amdgcn_rsqf(s.x),
-                   s.y == eps2 ? 0.f : __builtin_amdgcn_rsqf(s.y)};
+    // Potential mode: 1/sqrt(s) of a source pair.  A source at zero distance (s == eps^2) is
+    // kept out of the float sum -- the body itself is one, its own leaf always delivers it, and
+    // its m_i / eps can be 10^3 times all the other terms together (a heavy body, a small
+    // softening), which would cost the sum its low digits -- and its mass goes to msame2
+    // instead.  At the end msame - m_i is the mass of the OTHER sources at zero distance
+    // (bodies at the same position, a node whose centre of mass falls on the body): exactly 0
+    // in nearly every case, and their m / eps is added then.
+    v2f msame2 = {0.f, 0.f};
+    auto pot_rsq = [&](const v2f s, const v2f m) -> v2f {
+        const bool z0 = s.x == eps2, z1 = s.y == eps2;
+        msame2 += v2f{z0 ? m.x : 0.f, z1 ? m.y : 0.f};
+        return v2f{z0 ? 0.f : __builtin_amdgcn_rsqf(s.x), z1 ? 0.f : __builtin_amdgcn_rsqf(s.y)};
     };
     auto pair_force = [&](const v4f a, const v4f c) {
         if (MODE == TRAV_WALK_ONLY) {  // keep the LDS reads alive, skip the arithmetic
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
         const v2f s = __builtin_elementwise_fma(
             dz, dz, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dx, dx, e2)));
         if (MODE == TRAV_POTENTIAL) {   // fx2 doubles as the potential accumulator
-            fx2 = __builtin_elementwise_fma(pot_rsq(s), c.zw, fx2);
+            fx2 = __builtin_elementwise_fma(pot_rsq(s, c.zw), c.zw, fx2);
             return;
         }
         const v2f s3 = s * s * s;
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
         const v2f s = __builtin_elementwise_fma(
             dz, dz, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dx, dx, e2)));
         if (MODE == TRAV_POTENTIAL) {
-            fx2 = __builtin_elementwise_fma(pot_rsq(s), v2f{r[6], r[7]}, fx2);
+            fx2 = __builtin_elementwise_fma(pot_rsq(s, v2f{r[6], r[7]}), v2f{r[6], r[7]}, fx2);
             return;
         }
         const v2f s3 = s * s * s;
@@ -563,8 +568,11 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
     }
 #endif
     if (MODE == TRAV_POTENTIAL) {
+        float ms = msame2.x + msame2.y;
+        if constexpr (G == 32) ms += __shfl_xor(ms, 32, 64);
         if (active) {
-            const float p = fx;   // the body's own term never entered the sum (pot_rsq)
+            // the body's own term never entered the sum; other sources at zero distance do now
+            const float p = fx + (ms - me.w) * __builtin_amdgcn_rsqf(eps2);
             tail->pot[b] = (accumulate & 1) ? tail->pot[b] + p : p;
         }
         return;

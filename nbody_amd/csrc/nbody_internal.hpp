@@ -265,6 +265,7 @@ int sample_ic_range(int kind, long long first, int count, long long n_total, uin
                     float *vy, float *vz, float *m);
 
 // ---- on-device reductions (k_reduce.hip) ----
+void noalloc_prepare_current_device();   // resolves nbody_direct_energy_dev_noalloc's scratch address
 size_t reduce_scratch_bytes(int blocks, int k);
 // out[0] = sum m v^2/2, out[1] = -G/2 sum m pot, out[2] = sum |a - d| / |d| (a, d nullable)
 hipError_t launch_energy_reduce(int n, const float *m, int m_stride, const float *vx, const float *vy,

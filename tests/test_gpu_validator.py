@@ -126,6 +126,45 @@ def test_tree_energy_matches_all_pairs_energy(theta, rtol):
     assert abs((ke + pe) - e_ref) <= rtol * abs(e_ref), (ke + pe, e_ref)
 
 
+def test_tree_energy_counts_coincident_bodies_like_the_all_pairs_energy():
+    """Bodies at the SAME position (clamped into a wall corner, or equal by construction) are
+    sources of each other at zero distance: m_j / eps each.  Only a body's own term is left
+    out, as the reference leaves out idx == i (src/cuda/validator.cu:101), not everything at
+    zero distance."""
+    import torch
+    n = 4096
+    ic = nb.sample_ic(nb.IC_SPHERE, n, 12)
+    for k in "xyz":                                   # 1200 bodies in 400 triplets of one position
+        ic[k][400:800] = ic[k][:400]
+        ic[k][800:1200] = ic[k][:400]
+    ic["m"] = (ic["m"] * np.linspace(0.5, 1.5, n)).astype(np.float32)   # unequal masses
+    eps = 0.05
+    p = nb.Params(num_points=n, theta=0.0, dt=1e-3, softening_factor=eps, morton_bits=21)
+    with nb.Simulation(p) as sim:
+        sim.set_state(ic["x"], ic["y"], ic["z"], ic["m"])
+        ke, pe = sim.tree_energy()
+        st = sim.get_state()
+    e_ref = O.energy_f64(st["x"], st["y"], st["z"], st["vx"], st["vy"], st["vz"], st["m"], eps, 1.0)
+    assert abs((ke + pe) - e_ref) <= 5e-5 * abs(e_ref), (ke + pe, e_ref)
+    # and the all-pairs energy on the device agrees as well
+    posm = torch.from_numpy(np.stack([st["x"], st["y"], st["z"], st["m"]], 1).astype(np.float32)).cuda()
+    v = [torch.zeros(n, dtype=torch.float32, device="cuda") for _ in range(3)]
+    out = torch.full((2,), np.nan, dtype=torch.float64, device="cuda")
+    rc = nb.load_library().nbody_direct_energy_dev(posm.data_ptr(), v[0].data_ptr(), v[1].data_ptr(), v[2].data_ptr(),
+                                                   n, eps, 1.0, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert abs(out.cpu().numpy()[1] - pe) <= 5e-5 * abs(pe)
+    # the coincident bodies matter at this tolerance: without their mutual terms the energy is off
+    m = st["m"].astype(np.float64)
+    same = 0.0
+    key = np.stack([st["x"], st["y"], st["z"]], 1)
+    _, inv, cnt = np.unique(key, axis=0, return_inverse=True, return_counts=True)
+    for g in np.flatnonzero(cnt > 1):
+        mg = m[inv.ravel() == g]
+        same += (mg.sum() ** 2 - (mg ** 2).sum()) / 2 / eps
+    assert same > 2e-4 * abs(e_ref)
+
+
 @pytest.mark.parametrize("kind,n,eps", [(nb.IC_DISK, 20000, 0.01), (nb.IC_PLUMMER, 4097, 0.02),
                                         (nb.IC_SPHERE, 1, 0.1), (nb.IC_DISK, 255, 1e-3)])
 def test_direct_energy_on_device_matches_oracle(kind, n, eps):
