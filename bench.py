@@ -50,7 +50,10 @@ BUILD_BYTES_PER_PARTICLE = {10: 64 + 4 + 4 * 16 + 100 + 12 + 16 + 20,        # 3
 PEAK_FP32_TFLOPS = 157.3           # MI355X FP32 vector peak
 PEAK_FP64_TFLOPS = 78.6            # MI355X FP64 vector peak
 PEAK_HBM_GBS = 8000.0              # MI355X HBM3E peak
-SUSTAINED_CLOCK_GHZ = 2.0          # shader clock measured inside k_traverse (profiles/r1_walk_profile.txt)
+# shader clock measured inside k_traverse with the profiling build (s_memtime against
+# s_memrealtime over 400 back-to-back steps): 2.26-2.30 GHz on the box of profiles/r3_walk_profile.txt;
+# an earlier box held 2.0 GHz (profiles/r1_walk_profile.txt) -- devices differ
+SUSTAINED_CLOCK_GHZ = 2.28
 REFERENCE_MS_PER_STEP = 150.0      # reference README, RTX 500 Ada, 2,097,152 particles, theta=0.6
 
 
@@ -590,7 +593,7 @@ def main():
     if world == 1 and not args.no_direct_sum and not args.walk_only:
         direct = direct_sum_block(args.no_cpu_baseline)
     traffic, traffic_src = None, None
-    for name in ("r2_traffic.json", "r1_traffic.json"):
+    for name in ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 traffic = json.load(f)["k_traverse"]["bytes"]
@@ -665,15 +668,20 @@ def main():
                                                  "per two sources: the instruction-issue floor of the force "
                                                  "arithmetic on 1024 SIMDs, at the nominal 2.4 GHz and at the "
                                                  "clock measured inside this kernel (s_memtime against "
-                                                 "s_memrealtime, profiles/r1_walk_profile.txt)"}},
+                                                 "s_memrealtime, profiles/r3_walk_profile.txt; another box "
+                                                 "measured 2.0 GHz)"}},
             "roofline_build": {"bound": "hbm", "achieved": round(build_gbs, 1), "peak": PEAK_HBM_GBS,
                                "unit": "GB/s", "frac": round(build_gbs / PEAK_HBM_GBS, 4),
                                "bytes_per_particle": build_bytes,
                                "note": f"{build_bytes} algorithmic B/particle over integrate+sort+permute+"
                                        f"build+COM with the {3 * args.morton_bits}-bit keys this run used "
                                        f"({BUILD_BYTES_PER_PARTICLE[10]} with 30-bit keys, "
-                                       f"{BUILD_BYTES_PER_PARTICLE[21]} with 63-bit keys); these kernels are "
-                                       "dependency-latency-bound at this size, not bandwidth-bound"},
+                                       f"{BUILD_BYTES_PER_PARTICLE[21]} with 63-bit keys); the same GB/s at "
+                                       "16.7 M particles (build time is linear in N): the digit passes run at "
+                                       "2.6 TB/s whatever the ranking and the load latency cost "
+                                       "(profiles/r3_sort_pass_experiments.txt), the waves of the tree and "
+                                       "centre-of-mass kernels wait 80-85 % of their cycles on dependent loads "
+                                       "(profiles/r3_build_kernels_pmc_2M_16M.txt)"},
         }
         if world > 1:
             out["rccl_world"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),

@@ -41,6 +41,8 @@ struct DD {
     nbody_comm comm{};
     int T = LET_MAX_T;
     float *fr_send = nullptr, *fr_all = nullptr;
+    uint32_t *box_all = nullptr;     // [6W] gathered bounding boxes (fitted key domain)
+    uint32_t *box_mine = nullptr;    // [6] neutral box of a domain without particles
     unsigned char *exp_buf = nullptr;   // [W] segments of exp_cap bytes: the copy for each domain
     size_t exp_cap = 0;
     int32_t *cnt_dev = nullptr;      // [4W]: (nodes, records) per destination, then per origin
@@ -162,6 +164,30 @@ int lower_bounds(DD *d, const std::vector<uint64_t> &q, std::vector<int32_t> &lb
     return NBODY_OK;
 }
 
+// Sim::bbox_hook of a handle with a fitted key domain: the box of all ranks' particles.
+int dd_bbox_hook(void *ctx, uint32_t *box_dev, hipStream_t stream)
+{
+    DD *d = static_cast<DD *>(ctx);
+    const int W = d->comm.size;
+    if (W == 1) return 0;
+    if (d->comm.all_gather(d->comm.ctx, box_dev, d->box_all, 6 * sizeof(uint32_t), (void *) stream) != 0) return 1;
+    return launch_bbox_merge(d->box_all, W, box_dev, stream) == hipSuccess ? 0 : 1;
+}
+
+// A domain without particles runs no kick-drift, but the others wait for its (neutral) box.
+int empty_domain_bbox(DD *d)
+{
+    Sim *s = d->own;
+    if (!s->keybox) return NBODY_OK;
+    const uint32_t neutral[6] = {0x7f7fffffu, 0x7f7fffffu, 0x7f7fffffu, 0u, 0u, 0u};
+    DD_HIP(d, hipMemcpyAsync(d->box_mine, neutral, sizeof neutral, hipMemcpyHostToDevice, s->stream));
+    if (dd_bbox_hook(d, d->box_mine, s->stream) != 0) return dfail(d, NBODY_ERR_STATE, "collective failed: bounding boxes");
+    // the cube every other rank draws from the merged box: keep this rank's copy in step
+    DD_HIP(d, hipMemcpyAsync(reinterpret_cast<uint32_t *>(s->keybox + 5), d->box_mine, sizeof neutral, hipMemcpyDeviceToDevice, s->stream));
+    DD_HIP(d, launch_keyfit_only(s));
+    return NBODY_OK;
+}
+
 int ctz_edge(uint64_t j, int width)   // trailing zeros of an edge index; the ends count as coarsest
 {
     if (j == 0 || j == (1ull << width)) return 64;
@@ -234,7 +260,7 @@ int nbody_dd_create(nbody_t *own, const nbody_comm *comm, nbody_dd_t **out)
         return NBODY_ERR_INVALID;
     *out = nullptr;
     Sim *s = reinterpret_cast<Sim *>(own);
-    if (s->fp64 || s->keybox) return NBODY_ERR_STATE;   // one common key space: no fitted keys
+    if (s->fp64) return NBODY_ERR_STATE;
     DD *d = new (std::nothrow) DD();
     if (!d) return NBODY_ERR_INVALID;
     d->own = s;
@@ -245,6 +271,8 @@ int nbody_dd_create(nbody_t *own, const nbody_comm *comm, nbody_dd_t **out)
     auto A = [&](void **p, size_t bytes) { return hipMalloc(p, std::max<size_t>(bytes, 16)); };
     hipError_t e = A((void **) &d->fr_send, (size_t) d->T * LET_REC * sizeof(float));
     if (e == hipSuccess) e = A((void **) &d->fr_all, (size_t) W * d->T * LET_REC * sizeof(float));
+    if (e == hipSuccess) e = A((void **) &d->box_all, (size_t) 6 * W * sizeof(uint32_t));
+    if (e == hipSuccess) e = A((void **) &d->box_mine, 6 * sizeof(uint32_t));
     if (e == hipSuccess) e = A((void **) &d->cnt_dev, (size_t) 4 * W * sizeof(int32_t));
     if (e == hipSuccess) e = hipHostMalloc((void **) &d->cnt_host, (size_t) 4 * W * sizeof(int32_t));
     if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_counts, hipEventDisableTiming);
@@ -262,6 +290,23 @@ int nbody_dd_create(nbody_t *own, const nbody_comm *comm, nbody_dd_t **out)
     }
     d->splitters.assign((size_t) W + 1, 0);
     d->splitters[W] = 1ull << key_bits(s);
+    if (s->keybox) {
+        // Fitted key domain: all ranks must encode relative to one cube.  From here on the cube
+        // is decided from the union of the ranks' bounding boxes; the cube this handle may have
+        // drawn for itself is dropped, so that the first collective decision starts from the
+        // same state everywhere (particles come through nbody_dd_spawn, which re-encodes them).
+        if (s->spawned && W > 1) {
+            nbody_dd_destroy(reinterpret_cast<nbody_dd_t *>(d));
+            return NBODY_ERR_STATE;
+        }
+        const float zero = 0.f;
+        if (hipMemcpy(s->keybox + 4, &zero, sizeof zero, hipMemcpyHostToDevice) != hipSuccess) {
+            nbody_dd_destroy(reinterpret_cast<nbody_dd_t *>(d));
+            return NBODY_ERR_HIP;
+        }
+        s->bbox_hook = dd_bbox_hook;
+        s->bbox_hook_ctx = d;
+    }
     // update() = build only: forces and kick are driven from here
     if (nbody_set_traversal_range(own, 0, 0) != NBODY_OK) {
         nbody_dd_destroy(reinterpret_cast<nbody_dd_t *>(d));
@@ -278,6 +323,8 @@ void nbody_dd_destroy(nbody_dd_t *h)
     Guard g(d->own->device);
     (void) hipStreamSynchronize(d->own->stream);
     auto F = [](void *p) { if (p) (void) hipFree(p); };
+    if (d->own->bbox_hook_ctx == d) { d->own->bbox_hook = nullptr; d->own->bbox_hook_ctx = nullptr; }
+    F(d->box_all); F(d->box_mine);
     F(d->fr_send); F(d->fr_all); F(d->exp_buf); F(d->cnt_dev); F(d->recv_buf); F(d->q_dev); F(d->lb_dev);
     F(d->hist_dev); F(d->hist_all); F(d->mig_send); F(d->mig_recv);
     if (d->cnt_host) (void) hipHostFree(d->cnt_host);
@@ -307,6 +354,7 @@ int nbody_dd_step(nbody_dd_t *h)
     d->phases_valid = false;
     DD_HIP(d, mark(0));
     if (have) DD_NB(d, nbody_update(H(s)));
+    else if (W > 1) { int rce = empty_domain_bbox(d); if (rce) return rce; }
     DD_HIP(d, mark(1));
     if (W == 1) {
         if (have) {
@@ -577,6 +625,8 @@ int nbody_dd_rebalance(nbody_dd_t *h)
         return dfail(d, NBODY_ERR_CAPACITY, "rebalance: the domain would hold more particles than num_points");
     }
     if (total_recv == 0) {
+        int rce = empty_domain_bbox(d);   // the others re-encode what they received
+        if (rce) return rce;
         DD_HIP(d, hipStreamSynchronize(s->stream));
         s->n = 0;
         s->spawned = false;

@@ -288,6 +288,22 @@ __global__ __launch_bounds__(256) void k_twin_kick_drift(int n, float dt, float 
 
 static inline int nblk(int n, int t) { return (n + t - 1) / t; }
 
+// Boxes of `ranks` domains (6 words each, gathered) -> their union, into box[6].
+__global__ void k_bbox_merge(const uint32_t *__restrict__ all, int ranks, uint32_t *box)
+{
+    const int k = threadIdx.x;
+    if (k >= 6) return;
+    uint32_t v = all[k];
+    for (int r = 1; r < ranks; ++r) v = k < 3 ? min(v, all[6 * r + k]) : max(v, all[6 * r + k]);
+    __hip_atomic_store(&box[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+hipError_t launch_bbox_merge(const uint32_t *all_dev, int ranks, uint32_t *box_dev, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_bbox_merge, dim3(1), dim3(64), 0, st, all_dev, ranks, box_dev);
+    return hipGetLastError();
+}
+
 hipError_t launch_twin_kick_drift(int n, float dt, float domain, Float4 *posm, const float *vx,
                                   const float *vy, const float *vz, const float *ax,
                                   const float *ay, const float *az, float *vhx, float *vhy,
@@ -305,6 +321,8 @@ hipError_t launch_vel_kick_raw(int n, float dt, float keep, const float *vhx, co
 static hipError_t launch_fit_and_encode(Sim *s)
 {
     const int c = s->cur;
+    if (s->bbox_hook && s->bbox_hook(s->bbox_hook_ctx, reinterpret_cast<uint32_t *>(s->keybox + 5), s->stream) != 0)
+        return hipErrorUnknown;
     hipLaunchKernelGGL(k_keyfit, dim3(1), dim3(1), 0, s->stream, s->keybox, s->p.domain_size);
     if (s->key_bytes == 4)
         hipLaunchKernelGGL(k_morton<uint32_t>, dim3(nblk(s->n, 256)), dim3(256), 0, s->stream, s->n,
@@ -312,6 +330,12 @@ static hipError_t launch_fit_and_encode(Sim *s)
     else
         hipLaunchKernelGGL(k_morton<uint64_t>, dim3(nblk(s->n, 256)), dim3(256), 0, s->stream, s->n,
                            s->p.domain_size, s->keybox, s->x[c], s->y[c], s->z[c], (uint64_t *) s->keys[0]);
+    return hipGetLastError();
+}
+
+hipError_t launch_keyfit_only(Sim *s)
+{
+    hipLaunchKernelGGL(k_keyfit, dim3(1), dim3(1), 0, s->stream, s->keybox, s->p.domain_size);
     return hipGetLastError();
 }
 

@@ -122,6 +122,11 @@ struct Sim {
     // fitted key domain (NBODY_FLAG_FIT_KEYS): lo xyz, side, valid + 6 words of bounding-box
     // scratch, device memory; null = keys span [0, domain_size]^3 like the reference's
     float *keybox = nullptr;
+    // With several domains (nbody_dd_*) every rank must draw the SAME cube: between the bounding
+    // box of the own particles and the decision (k_keyfit) this hook turns the six box words
+    // (device, min xyz / max xyz as bit patterns) into the box of ALL ranks' particles.
+    int (*bbox_hook)(void *ctx, uint32_t *box_dev, hipStream_t stream) = nullptr;
+    void *bbox_hook_ctx = nullptr;
 
     // sort
     void *keys[2]{};              // KeyT[n] ping-pong
@@ -213,6 +218,8 @@ struct Sim {
 // ---- stage launchers (each enqueues on s->stream and returns a hipError_t) ----
 hipError_t launch_integrate_morton(Sim *s);                 // kick-drift + encode -> keys[0]
 hipError_t launch_morton_only(Sim *s);                      // encode current positions
+hipError_t launch_keyfit_only(Sim *s);                      // cube decision from the box words
+hipError_t launch_bbox_merge(const uint32_t *all_dev, int ranks, uint32_t *box_dev, hipStream_t st);
 hipError_t launch_sort(Sim *s);                             // keys/vals -> sorted keys, perm
 hipError_t launch_permute(Sim *s, bool all_fields);         // gather by perm, write posm
 hipError_t launch_build(Sim *s);                            // unique .. octree emit

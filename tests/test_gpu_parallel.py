@@ -129,13 +129,17 @@ def test_domain_decomposition_single_rank_is_a_plain_step(single_rank_group):
         assert np.array_equal(sa[k], sb[k]), k
 
 
-@pytest.mark.parametrize("flags", [nb.FLAG_FP64, nb.FLAG_FIT_KEYS])
-def test_domain_decomposition_refuses_handles_it_cannot_step(single_rank_group, flags):
-    """The exchange is float-only and every rank must share one key cube: a double handle and a
-    handle with a fitted key domain are refused when the stepper is created, not later."""
-    with nb.Simulation(nb.Params(num_points=1000, device_id=0, flags=flags)) as sim:
+def test_domain_decomposition_refuses_handles_it_cannot_step(single_rank_group):
+    """The exchange is float-only: a double handle is refused when the stepper is created, not
+    later.  A handle with a fitted key domain is accepted (the ranks then draw one cube together)."""
+    with nb.Simulation(nb.Params(num_points=1000, device_id=0, flags=nb.FLAG_FP64)) as sim:
         with pytest.raises(RuntimeError, match="nbody_dd_create failed"):
             parallel.DomainDecomposition(sim, "cuda:0")
+    with nb.Simulation(nb.Params(num_points=1000, morton_bits=10, device_id=0, flags=nb.FLAG_FIT_KEYS)) as sim:
+        with parallel.DomainDecomposition(sim, "cuda:0") as dd:
+            dd.spawn(nb.IC_SPHERE, 1000)
+            dd.step()
+            assert dd.stats()["n_local"] == 1000 and np.isfinite(sim.get_state()["ax"]).all()
 
 
 def test_torch_comm_callbacks_single_rank_nccl(single_rank_group):
@@ -169,10 +173,11 @@ import nbody_amd as nb
 from nbody_amd import parallel
 rank, world, n = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(sys.argv[2])
 bits = int(sys.argv[4])
+fit = nb.FLAG_FIT_KEYS if len(sys.argv) > 5 and sys.argv[5] == "fit" else 0
 dist.init_process_group("gloo", rank=rank, world_size=world)
 cap = int(n / world * 1.5) + 64                      # head-room for the re-balance
 sim = nb.Simulation(nb.Params(num_points=cap, morton_bits=bits, theta=0.6, dt=1e-3,
-                              softening_factor=0.01, device_id=0, seed=5, flags=nb.FLAG_TIMING))
+                              softening_factor=0.01, device_id=0, seed=5, flags=nb.FLAG_TIMING | fit))
 dd = parallel.DomainDecomposition(sim, "cuda:0", via_host=True)
 dd.spawn(nb.IC_SPHERE, n)
 st0 = dd.stats()
@@ -188,7 +193,7 @@ s = sim.get_state()
 t = sim.get_timings()
 np.savez(sys.argv[3] + f"/rank{rank}.npz", gid=s["id"], gid1=s1["id"], keys0=keys0,
          split=np.array(st0["splitters"], np.uint64), sent=st1["records_sent"], recv=st1["records_received"],
-         n0=st0["n_local"], steps=t["steps"], inter=t["interactions"],
+         n0=st0["n_local"], steps=t["steps"], inter=t["interactions"], cube=np.asarray(sim.key_domain(), np.float32),
          **{k: s[k] for k in ("x", "y", "z", "m", "ax", "ay", "az")},
          **{k + "1": s1[k] for k in ("x", "y", "z", "m", "ax", "ay", "az")})
 dist.barrier()
@@ -198,8 +203,9 @@ dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("world,n,bits", [(2, 12000, 21), (3, 9000, 21), (4, 8000, 10)])
-def test_native_domain_decomposition_processes_share_the_gpu(tmp_path, world, n, bits):
+@pytest.mark.parametrize("world,n,bits,fit", [(2, 12000, 21, False), (3, 9000, 21, False), (4, 8000, 10, False),
+                                              (3, 9000, 10, True), (2, 8000, 10, True)])
+def test_native_domain_decomposition_processes_share_the_gpu(tmp_path, world, n, bits, fit):
     """nbody_dd_spawn / step / rebalance with `world` ranks (processes that share this GPU; the
     collectives are staged through host memory and gloo): ownership is by Morton-key range,
     every particle is owned once, forces checked against a float64 direct sum over all
@@ -211,7 +217,7 @@ def test_native_domain_decomposition_processes_share_the_gpu(tmp_path, world, n,
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(n), str(tmp_path), str(bits)],
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(n), str(tmp_path), str(bits)] + (["fit"] if fit else []),
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                                       text=True))
     for p in procs:
@@ -235,6 +241,10 @@ def test_native_domain_decomposition_processes_share_the_gpu(tmp_path, world, n,
         # (inside a uniform sphere the forces largely cancel: the single-tree code is at 3e-3 here)
         errs[tag] = (mean, mx)
         assert mean < 1e-2 and mx < 0.3, (tag, mean, mx)
+    if fit:   # 30-bit keys relative to ONE cube, fitted to all ranks' particles together
+        cube = res[0]["cube"]
+        assert all(np.array_equal(d["cube"], cube) for d in res)
+        assert 1.0 < cube[3] < 1.6 and np.all(cube[:3] > 1.6) and np.all(cube[:3] + cube[3] < 3.4), cube
     for r, d in enumerate(res):
         assert np.array_equal(d["split"], split)
         # after the spawn every rank holds exactly its key range, about n / world particles
@@ -245,7 +255,7 @@ def test_native_domain_decomposition_processes_share_the_gpu(tmp_path, world, n,
     # first step against the single-handle tree code on the same particles (same positions:
     # v = a = 0 at the first kick-drift; forces differ by the trees only)
     with nb.Simulation(nb.Params(num_points=n, morton_bits=bits, theta=0.6, dt=1e-3,
-                                 softening_factor=0.01)) as one:
+                                 softening_factor=0.01, flags=nb.FLAG_FIT_KEYS if fit else 0)) as one:
         one.set_state(ic["x"], ic["y"], ic["z"], ic["m"])
         one.update()
         s1 = one.get_state()

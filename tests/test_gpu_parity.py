@@ -492,7 +492,8 @@ def test_tiny_node_stack_gives_the_same_lists(kind, n, bits, theta):
 def test_headline_workload_first_step_matches_oracle():
     """The benchmark's own workload at full size (2,097,152-particle sphere, theta = 0.6,
     eps = 0.1, 63-bit keys): tree sizes, every group's interaction-list length and the exact
-    interaction total equal the host oracle's; accelerations within the float tolerance."""
+    interaction total equal the host oracle's; accelerations within the float tolerance; the
+    sampled error against a float64 direct sum inside its stated band."""
     n, theta, eps, dt = 2_097_152, 0.6, 0.1, 1e-6
     ic = nb.sample_ic(nb.IC_SPHERE, n, 42)
     with new_sim(n, morton_bits=21, theta=theta, dt=dt, softening_factor=eps,
@@ -502,6 +503,13 @@ def test_headline_workload_first_step_matches_oracle():
         gpu = sim.get_octree()
         st = sim.get_state()
         tim = sim.get_timings()
+        d64 = sim.direct_sum(np.float64)        # float64 direct sum at the same positions, on the GPU
+    # Accuracy of the headline configuration, stated: monopoles at theta = 0.6 inside a
+    # homogeneous sphere, where the attractions nearly cancel and a relative measure is
+    # inflated -- mean 1.5e-2, max 5.4e-2 on the 4096 bodies the benchmark samples.
+    pick = np.random.default_rng(1).choice(n, 4096, replace=False)
+    mean_e, max_e = O.acc_error(st["ax"][pick], st["ay"][pick], st["az"][pick], *[a[pick] for a in d64])
+    assert 5e-3 < mean_e < 2e-2 and max_e < 8e-2, (mean_e, max_e)
     ref0 = O.full_build(ic["x"], ic["y"], ic["z"], ic["m"], 5.0, 21, 32)   # the spawn build
     # v = a = 0: the first update does not move anything and re-sorts sorted particles
     ref = O.full_build(ref0["xs"], ref0["ys"], ref0["zs"], ref0["ms"], 5.0, 21, 32)
