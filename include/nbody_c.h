@@ -67,9 +67,19 @@ enum {
                                           is at least 0.4 of its side, and is otherwise re-drawn
                                           around their bounding box (side = 1.25 x the largest
                                           extent), on the device; octree cells subdivide it, so
-                                          node sizes are side / 2^level.  Float handles only, and
-                                          not for nbody_dd_* (the ranks need one common key
-                                          space).  nbody_get_key_domain() returns the cube.   */
+                                          node sizes are side / 2^level.  Float handles only;
+                                          under nbody_dd_* the ranks draw one cube together.
+                                          nbody_get_key_domain() returns the cube.            */
+    NBODY_FLAG_NO_UNIFORM_MASS = 1u << 5, /* When every particle handed to set_state / spawn has
+                                          the same mass m0, a float handle with groups of 64
+                                          leaves the mass out of the particle-particle
+                                          arithmetic (one packed multiply of the fourteen
+                                          instructions per source pair) and scales the sums by
+                                          m0 at the end: interaction lists unchanged, forces the
+                                          same bits when m0 is a power of two, within a few
+                                          float roundings otherwise.  This flag keeps the
+                                          general kernel (the reference multiplies by the
+                                          mass per pair, include/cuda/physics_common.cuh:62-75). */
     NBODY_FLAG_DEBUG_SMALL_STACK = 1u << 9, /* test aid: the traversal runs with a node stack of
                                             32 usable entries, so that its overflow handling
                                             (push-backs, depth-first rounds) is exercised;

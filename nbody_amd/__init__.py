@@ -24,6 +24,7 @@ FLAG_NO_FUSED_VEL = 1 << 1
 FLAG_TIMING_STAGES = 1 << 2
 FLAG_FP64 = 1 << 3
 FLAG_FIT_KEYS = 1 << 4
+FLAG_NO_UNIFORM_MASS = 1 << 5
 FLAG_DEBUG_WALK_ONLY = 1 << 8
 FLAG_DEBUG_SMALL_STACK = 1 << 9
 

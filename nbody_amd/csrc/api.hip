@@ -381,6 +381,11 @@ int upload_state_r(Sim *s, St &a, R4 *tw_posm, R *const tw_v[3], R *const tw_a[3
     const int c = s->cur;
     std::vector<uint32_t> ids(n);
     for (size_t i = 0; i < n; ++i) ids[i] = (uint32_t) i;
+    {   // all masses equal (and a normal positive float)?
+        bool uni = n > 0 && m[0] > R(1e-30) && m[0] < R(1e30);
+        for (size_t i = 1; uni && i < n; ++i) uni = m[i] == m[0];
+        s->uniform_mass = uni ? (float) m[0] : 0.f;
+    }
     NB_HIP(s, hipMemcpyAsync(a.x[c], x, b, hipMemcpyHostToDevice, s->stream));
     NB_HIP(s, hipMemcpyAsync(a.y[c], y, b, hipMemcpyHostToDevice, s->stream));
     NB_HIP(s, hipMemcpyAsync(a.z[c], z, b, hipMemcpyHostToDevice, s->stream));
@@ -575,6 +580,7 @@ int install_particles_dev(Sim *s, int n)
     if (s->fp64) return fail(s, NBODY_ERR_STATE, "install_particles: float handles only");
     if (n < 1 || n > s->cap) return fail(s, NBODY_ERR_CAPACITY, "install_particles: count outside [1, num_points]");
     s->n = n;
+    s->uniform_mass = 0.f;   // particles of other ranks: their masses are not known here
     NB_HIP(s, hipMemsetAsync(s->counts, 0, sizeof(Counts), s->stream));
     NB_HIP(s, launch_morton_only(s));
     int rc = build_after_encode(s, true);   // permutes x,y,z,m,v,vh,id: the accelerations ride in vh
@@ -1278,6 +1284,7 @@ int nbody_set_sources_dev(nbody_t *h, const float *posm_dev, int32_t count)
         return fail(s, NBODY_ERR_STATE, "set_sources on a handle with a validator");
     s->n = count;
     s->pending_vel = false;
+    s->uniform_mass = 0.f;
     if (count == 0) { s->spawned = false; return NBODY_OK; }
     NB_HIP(s, hipMemsetAsync(s->counts, 0, sizeof(Counts), s->stream));
     NB_HIP(s, launch_unpack_sources(s, reinterpret_cast<const Float4 *>(posm_dev), count));

@@ -80,14 +80,20 @@ struct alignas(16) WaveLds {
 // distance -- the body itself -- left out; writes tail->pot and nothing else).
 constexpr int TRAV_FORCE = 0, TRAV_WALK_ONLY = 1, TRAV_POTENTIAL = 2;
 
-template <int G, bool FUSE_VEL, int MODE>
+// UNI (G = 64, forces only): every particle has the same mass m0.  Particles streamed through
+// the scalar path then skip the multiplication by their mass; the masses of the ring's entries
+// (accepted nodes, odd particles at run ends) are divided by m0 on their way in and the caller
+// passes gravity * m0, so that every sum is in units of m0.  With m0 = 1 (or any power of two)
+// the result is the same bits as the general path's.
+template <int G, bool FUSE_VEL, int MODE, bool UNI = false>
 __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
     int n, int g0, int g1, const Float4 *__restrict__ body_posm, const Float4 *__restrict__ posm,
     const v8f *__restrict__ posm2, const Float4 *__restrict__ nodeA,
     const NodeB *__restrict__ nodeB, float theta, float eps2, float gravity, float domain,
     float dt, float keep, const TravTail *__restrict__ tail, int cur, int accumulate,
-    int stack_limit, const int32_t *__restrict__ roots, int nroots)
+    int stack_limit, const int32_t *__restrict__ roots, int nroots, float inv_m0)
 {
+    static_assert(!UNI || (G == 64 && MODE == TRAV_FORCE), "uniform-mass path: wave-wide groups, forces");
     __shared__ WaveLds lds[TRAV_WAVES];
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
         lxyf[4 * p + h] = v.x;
         lxyf[4 * p + 2 + h] = v.y;
         lzmf[4 * p + h] = v.z;
-        lzmf[4 * p + 2 + h] = v.w;
+        lzmf[4 * p + 2 + h] = UNI ? v.w * inv_m0 : v.w;
     };
     auto flush64 = [&]() {
         PROF_T0();
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
         }
         const v2f s3 = s * s * s;
         v2f inv = {__builtin_amdgcn_rsqf(s3.x), __builtin_amdgcn_rsqf(s3.y)};
-        inv *= v2f{r[6], r[7]};
+        if (!UNI) inv *= v2f{r[6], r[7]};
         fx2 = __builtin_elementwise_fma(dx, inv, fx2);
         fy2 = __builtin_elementwise_fma(dy, inv, fy2);
         fz2 = __builtin_elementwise_fma(dz, inv, fz2);
@@ -714,11 +720,15 @@ static hipError_t traverse_impl(Sim *s, Sim *src, bool fuse_vel, int acc_flag, b
         const int grid = per_xcd * 8;
         const float eps2 = s->p.softening_factor * s->p.softening_factor;
         const float keep = 1.0f - s->p.velocity_dampening;
-#define NB_TRAV(GG, FV, WO)                                                                      \
-    hipLaunchKernelGGL((k_traverse<GG, FV, (WO)>), dim3(grid), dim3(64 * TRAV_WAVES), 0, s->stream,    \
+#define NB_TRAV_U(GG, FV, WO, UU, GRAV, IM0)                                                     \
+    hipLaunchKernelGGL((k_traverse<GG, FV, (WO), UU>), dim3(grid), dim3(64 * TRAV_WAVES), 0, s->stream, \
                        s->n, g0, g1, s->posm, src->posm, (const v8f *) src->posm2, src->nodeA,       \
-                       src->nodeB, s->p.theta, eps2, s->p.gravity, s->p.domain_size, s->p.dt, keep,  \
-                       s->trav_tail, c, acc_flag, stack_limit, roots, nroots)
+                       src->nodeB, s->p.theta, eps2, GRAV, s->p.domain_size, s->p.dt, keep,          \
+                       s->trav_tail, c, acc_flag, stack_limit, roots, nroots, IM0)
+#define NB_TRAV(GG, FV, WO) NB_TRAV_U(GG, FV, WO, false, s->p.gravity, 1.0f)
+        // every source particle has mass m0 (the sources are this handle's own particles and
+        // nothing imported): the uniform-mass variant
+        const float m0 = (src == s && !forest && !(s->p.flags & NBODY_FLAG_NO_UNIFORM_MASS)) ? s->uniform_mass : 0.f;
         const bool walk_only = (s->p.flags & NBODY_FLAG_DEBUG_WALK_ONLY) != 0;
         // test aid: a node stack with 32 usable entries makes unexpanded push-backs and
         // depth-first single-node rounds the common case
@@ -727,12 +737,16 @@ static hipError_t traverse_impl(Sim *s, Sim *src, bool fuse_vel, int acc_flag, b
             if (s->group == 64) NB_TRAV(64, false, TRAV_POTENTIAL); else NB_TRAV(32, false, TRAV_POTENTIAL);
         } else if (walk_only) {
             if (s->group == 64) NB_TRAV(64, false, TRAV_WALK_ONLY); else NB_TRAV(32, false, TRAV_WALK_ONLY);
+        } else if (s->group == 64 && m0 > 0.f) {
+            if (fuse_vel) NB_TRAV_U(64, true, TRAV_FORCE, true, s->p.gravity * m0, 1.0f / m0);
+            else NB_TRAV_U(64, false, TRAV_FORCE, true, s->p.gravity * m0, 1.0f / m0);
         } else if (s->group == 64) {
             if (fuse_vel) NB_TRAV(64, true, TRAV_FORCE); else NB_TRAV(64, false, TRAV_FORCE);
         } else {
             if (fuse_vel) NB_TRAV(32, true, TRAV_FORCE); else NB_TRAV(32, false, TRAV_FORCE);
         }
 #undef NB_TRAV
+#undef NB_TRAV_U
 #if NB_WALK_PROFILE
         (void) hipStreamSynchronize(s->stream);
         unsigned long long h[8], z[8] = {0};

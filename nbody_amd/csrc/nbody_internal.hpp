@@ -118,6 +118,10 @@ struct Sim {
     Float4 *posm = nullptr;       // (x,y,z,m) in sorted order
     float *posm2 = nullptr;       // same, pair-interleaved: (x0,x1,y0,y1,z0,z1,m0,m1) per pair
     int cur = 0;                  // which buffer of each pair is current
+    // > 0: every particle has this mass (seen on the host when the state was uploaded): the
+    // traversal then leaves the mass out of the particle-particle arithmetic (one packed
+    // multiply in fourteen instructions per source pair) and scales at the end.  0 = unknown.
+    float uniform_mass = 0.f;
 
     // fitted key domain (NBODY_FLAG_FIT_KEYS): lo xyz, side, valid + 6 words of bounding-box
     // scratch, device memory; null = keys span [0, domain_size]^3 like the reference's

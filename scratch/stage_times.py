@@ -6,6 +6,8 @@ import nbody_amd as nb
 n, bits = int(sys.argv[1]), int(sys.argv[2])
 kind = sys.argv[3] if len(sys.argv) > 3 else "sphere"
 fit = nb.FLAG_FIT_KEYS if len(sys.argv) > 4 and sys.argv[4] == "fit" else 0
+if len(sys.argv) > 4 and sys.argv[4] == "nouni":
+    fit = nb.FLAG_NO_UNIFORM_MASS
 if kind == "disk":
     ic = nb.sample_ic(nb.IC_DISK, n, 42); kw = dict(theta=0.75, dt=1e-4, softening_factor=1e-3)
 else:

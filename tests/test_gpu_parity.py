@@ -670,3 +670,44 @@ def test_library_against_committed_fixtures(path):
     assert np.array_equal(s3["id"], g["after3_id"])
     for k in ("x", "y", "z"):
         assert np.max(np.abs(s3[k] - g["after3_" + k])) < 1e-4, k
+
+
+@pytest.mark.parametrize("m0,exact", [(1.0, True), (2.0 ** -21, True), (0.37, False)])
+def test_uniform_mass_variant_equals_the_general_kernel(m0, exact):
+    """When every particle has the same mass the traversal leaves it out of the particle-particle
+    arithmetic and scales at the end: same lists; the same bits when the mass is a power of two,
+    a few roundings otherwise; and against the oracle like any other run.  Unequal masses (one
+    body changed) take the general kernel, and so does NBODY_FLAG_NO_UNIFORM_MASS."""
+    n, theta, eps = 20000, 0.6, 0.02
+    ic = make_ic("sphere", n, 3)
+    m = np.full(n, m0, np.float32)
+    res = {}
+    for name, flags, mm in (("uni", 0, m), ("general", nb.FLAG_NO_UNIFORM_MASS, m)):
+        with new_sim(n, morton_bits=21, theta=theta, dt=1e-3, softening_factor=eps, flags=flags) as sim:
+            sim.set_state(ic["x"], ic["y"], ic["z"], mm)
+            sim.step(2)                       # the second step kicks with real accelerations
+            res[name] = (sim.get_state(), sim.get_octree()["list_len"])
+    (a, la), (b, lb) = res["uni"], res["general"]
+    assert np.array_equal(la, lb)
+    for k in ("ax", "ay", "az", "vx", "x"):
+        if exact:
+            assert np.array_equal(a[k], b[k]), k
+        else:
+            assert np.allclose(a[k], b[k], rtol=2e-5, atol=1e-5 * np.abs(b[k]).max()), k   # float32 sums of ~10^4 terms
+    ref = O.full_build(a["x"], a["y"], a["z"], a["m"], 5.0, 21, 32)
+    ax, ay, az, ll = O.traverse(ref["tree"], ref["com"], ref["xs"], ref["ys"], ref["zs"], ref["ms"],
+                                64, theta, eps, 1.0, 5.0)
+    assert np.array_equal(la, ll)
+    err = np.sqrt((a["ax"] - ax) ** 2 + (a["ay"] - ay) ** 2 + (a["az"] - az) ** 2)
+    assert (err / np.sqrt(ax.astype(np.float64) ** 2 + ay ** 2 + az ** 2)).max() < 1e-4
+    # one heavier body: no longer uniform, general kernel, still the oracle's forces
+    m2 = m.copy(); m2[7] = 3 * m0
+    with new_sim(n, morton_bits=21, theta=theta, dt=1e-3, softening_factor=eps) as sim:
+        sim.set_state(ic["x"], ic["y"], ic["z"], m2)
+        sim.update()
+        c = sim.get_state()
+    ref = O.full_build(c["x"], c["y"], c["z"], c["m"], 5.0, 21, 32)
+    ax, ay, az, _ = O.traverse(ref["tree"], ref["com"], ref["xs"], ref["ys"], ref["zs"], ref["ms"],
+                               64, theta, eps, 1.0, 5.0)
+    err = np.sqrt((c["ax"] - ax) ** 2 + (c["ay"] - ay) ** 2 + (c["az"] - az) ** 2)
+    assert (err / np.sqrt(ax.astype(np.float64) ** 2 + ay ** 2 + az ** 2)).max() < 1e-4
