@@ -57,7 +57,7 @@ void free_all(Sim *s)
     F(s->nodeA); F(s->nodeB); F(s->list_len); F(s->inter_dev); F(s->trav_tail); F(s->pot);
     F(s->tw_posm); F(s->tw_pot); F(s->ds_pot); F(s->let_boxes); F(s->let_counts);
     F(s->keybox); F(s->red_scratch); F(s->red_out); F(s->let_mask); F(s->let_seg); F(s->let_frontier);
-    F(s->let_reach); F(s->let_bsum); F(s->imp_roots); F(s->imp_desc);
+    F(s->depth_rows); F(s->let_reach); F(s->let_bsum); F(s->imp_roots); F(s->imp_desc);
     if (s->ev_ready) (void) hipEventDestroy(s->ev_ready);
     if (s->red_host) (void) hipHostFree(s->red_host);
     for (int k = 0; k < 3; ++k) { F(s->tw_v[k]); F(s->tw_vh[k]); F(s->tw_a[k]); F(s->ds_a[k]); }
@@ -115,22 +115,24 @@ int alloc_all(Sim *s)
     }
 
     // Scratch zeroed once per step, one allocation so that one memset does it:
-    //   build part: tickets[16] | scan_status[2][T] | dhist[256] | rank_status[R][256]
+    //   build part: tickets[16] | scan_status[2][2T] | dhist[256] | rank_status[R][256]
     //   sort part : ghist[8*256] | tickets[16] | status[P][rows][256]
     s->sort_tiles = (int) ((n + SORT_TILE - 1) / SORT_TILE);
     const int passes = s->key_bytes == 4 ? 4 : 8;
     s->sort_status_bytes = (8 * 256 + 16 + (size_t) passes * sort_status_rows(s->sort_tiles) * 256) * sizeof(uint32_t);
     s->max_scan_tiles = (int) ((n + 1023) / 1024);  // smallest compaction tile is 1024
     s->rank_tiles = (int) ((2 * n + SORT_TILE - 1) / SORT_TILE);
-    const size_t zwords = 16 + 2 * (size_t) s->max_scan_tiles + 256 + (size_t) sort_status_rows(s->rank_tiles) * 256;
+    // (a scan row = one word per tile, then one per group of tiles: dev_utils.hpp, lb2_exclusive_wave)
+    const size_t zwords = 16 + 4 * (size_t) s->max_scan_tiles + 256 + (size_t) sort_status_rows(s->rank_tiles) * 256;
     s->zero_bytes = (zwords * 4 + 15) / 16 * 16;
     NB_HIP(s, hipMalloc((void **) &s->zero_block, s->zero_bytes + s->sort_status_bytes));
     s->ghist = (uint32_t *) (s->zero_block + s->zero_bytes);
     uint32_t *zw = (uint32_t *) s->zero_block;
     s->tickets = zw;
     s->scan_status = zw + 16;
-    s->dhist = s->scan_status + 2 * (size_t) s->max_scan_tiles;
+    s->dhist = s->scan_status + 4 * (size_t) s->max_scan_tiles;
     s->rank_status = s->dhist + 256;
+    NB_HIP(s, dalloc(&s->depth_rows, (size_t) 2048 * 32));
     NB_HIP(s, dalloc(&s->com_counter, 2 * n));
     NB_HIP(s, hipMemsetAsync(s->com_counter, 0, 2 * n * 4, s->stream));
 

@@ -159,6 +159,47 @@ __device__ __forceinline__ uint32_t lb_exclusive_wave(uint32_t *status, int tile
     return excl;
 }
 
+// Two-level variant for launches whose tiles are all resident at once (a few hundred to a few
+// thousand tiles on 256 CUs).  With the one-level chain above the aggregates of all tiles
+// appear at about the same moment and tile t then reads its t predecessors 64 at a time --
+// t / 64 memory round trips for the last tiles.  Here tiles form groups of LBW_GROUP: a tile
+// sums the aggregates of the earlier tiles of its group (one round trip), the last tile of a
+// group publishes the group's total, and the chained look-back runs over one word per GROUP
+// (64 groups per round trip).  Same protocol and bounds as above; all 64 lanes must call it.
+constexpr int LBW_GROUP = 32;
+
+__device__ __forceinline__ uint32_t lb2_exclusive_wave(uint32_t *tile_status, uint32_t *group_status,
+                                                       int tile, uint32_t aggregate, uint32_t *err)
+{
+    const int l = lane_id();
+    const int g = tile / LBW_GROUP, j = tile % LBW_GROUP;
+    if (l == 0) lb_store(&tile_status[tile], LB_AGG | aggregate);
+    uint32_t v = 0;
+    if (l < j) v = lb_wait(&tile_status[g * LBW_GROUP + l], err) & LB_MASK;
+    const uint32_t in_excl = wave_sum_u32(v);
+    const bool leader = j == LBW_GROUP - 1;
+    const uint32_t group_total = in_excl + aggregate;
+    if (g == 0) {
+        if (leader && l == 0) lb_store(&group_status[0], LB_PREFIX | group_total);
+        return in_excl;
+    }
+    if (leader && l == 0) lb_store(&group_status[g], LB_AGG | group_total);
+    uint32_t gex = 0;
+    int base = g - 1;
+    while (true) {
+        const int t = base - l;
+        uint32_t w = LB_PREFIX;  // virtual groups before group 0: prefix 0
+        if (t >= 0) w = lb_wait(&group_status[t], err);
+        const unsigned long long pm = __ballot((w >> 30) == 2u);
+        const int first = pm ? (int) __builtin_ctzll(pm) : WAVE;  // nearest group with a prefix
+        gex += wave_sum_u32((l <= first) ? (w & LB_MASK) : 0u);
+        if (pm) break;
+        base -= WAVE;
+    }
+    if (leader && l == 0) lb_store(&group_status[g], LB_PREFIX | (gex + group_total));
+    return gex + in_excl;
+}
+
 // All tiles of a launch are resident at once, so inclusive prefixes spread from tile 0 at
 // LB_WINDOW tiles per memory round trip: the window, not the tile count, sets the pace.
 #ifndef NB_LB_WINDOW

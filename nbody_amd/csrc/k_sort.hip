@@ -36,20 +36,40 @@ __global__ __launch_bounds__(256) void k_sort_hist(const KeyT *__restrict__ keys
     __shared__ uint32_t h[NPASS * 256];
     for (int j = threadIdx.x + P0 * 256; j < NPASS * 256; j += 256) h[j] = 0;
     __syncthreads();
-    // Four consecutive keys per thread: the keys arrive in the previous step's order, so their
-    // upper digits repeat from one key to the next and equal neighbours share one LDS atomic.
-    const int stride = gridDim.x * 256 * 4;
-    for (int i0 = (blockIdx.x * 256 + threadIdx.x) * 4; i0 < n; i0 += stride) {
-        KeyT k[4];
+    // HK consecutive keys per thread and round (few workgroups: the hot bins take one global
+    // atomic per workgroup; many keys in flight per thread instead).  The keys arrive in the
+    // previous step's order, so their upper digits repeat from one key to the next: a wave
+    // whose HK x 64 keys agree in a digit adds them with one LDS atomic, and a thread's equal
+    // neighbours share one otherwise.
+    constexpr int HK = 16;
+    const int stride = gridDim.x * 256 * HK;
+    const int lane = threadIdx.x & 63;
+    for (int i0 = (blockIdx.x * 256 + threadIdx.x) * HK; i0 < n; i0 += stride) {
+        KeyT k[HK];
+        const int cntv = min(HK, n - i0);
+        if (cntv == HK) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) k[j] = i0 + j < n ? keys[i0 + j] : keys[i0];
-        const int cntv = min(4, n - i0);
+            for (int j = 0; j < HK; ++j) k[j] = keys[i0 + j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < HK; ++j) k[j] = keys[min(i0 + j, n - 1)];
+        }
+        const bool full = __all(cntv == HK);   // (lanes past n have left the loop)
 #pragma unroll
         for (int p = P0; p < NPASS; ++p) {
-            int run = 1;
             int d = (int) ((k[0] >> (8 * p)) & 255);
+            const int d0 = __builtin_amdgcn_readfirstlane(d);
+            bool same = d == d0;
 #pragma unroll
-            for (int j = 1; j < 4; ++j) {
+            for (int j = 1; j < HK; ++j) same = same && (int) ((k[j] >> (8 * p)) & 255) == d0;
+            if (full && __all(same)) {
+                const unsigned long long live = __ballot(true);
+                if (lane == (int) __builtin_ctzll(live)) atomicAdd(&h[p * 256 + d0], (uint32_t) HK * (uint32_t) __popcll(live));
+                continue;
+            }
+            int run = 1;
+#pragma unroll
+            for (int j = 1; j < HK; ++j) {
                 const int dj = (int) ((k[j] >> (8 * p)) & 255);
                 if (j < cntv) {
                     if (dj == d) ++run;
@@ -84,36 +104,47 @@ __global__ __launch_bounds__(256) void k_tiefix(KeyT *keys, uint32_t *vals, int 
                                                 uint32_t *long_count)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
     const bool in = i < n;
-    // own key and the TIE_REG - 1 that follow: from the neighbouring lanes where the wave has
-    // them (every lane takes part in the shuffles), from memory at the end of the wave
-    KeyT k[TIE_REG];
-    k[0] = in ? keys[i] : (KeyT) 0;
-#pragma unroll
-    for (int a = 1; a < TIE_REG; ++a) {
-        if (a == 2) {
-            // nearly always no key of the wave agrees with its successor: nothing starts here
-            const bool tie = in && i + 1 < n && (k[1] >> low_bits) == (k[0] >> low_bits);
-            if (!__any(tie)) return;
+    const int ci = in ? i : n - 1;
+    // a run starts where a key agrees (in its upper bits) with its successor and not with its
+    // predecessor; nearly always no key of the wave does and nothing is left to do
+    const KeyT k0 = keys[ci];
+    const KeyT kn = keys[min(ci + 1, n - 1)], kp = keys[max(ci - 1, 0)];
+    const KeyT h = k0 >> low_bits;
+    const bool head = in && i + 1 < n && (kn >> low_bits) == h && !(i > 0 && (kp >> low_bits) == h);
+    if (!head) return;
+    // only the heads go on (a few lanes of a wave).  Runs of two or three first: they are nearly
+    // all there is.
+    const KeyT k2 = keys[min(i + 2, n - 1)], k3 = keys[min(i + 3, n - 1)];
+    const bool t2 = i + 2 < n && (k2 >> low_bits) == h, t3 = t2 && i + 3 < n && (k3 >> low_bits) == h;
+    if (!t2) {   // two elements
+        if (kn < k0) {
+            const uint32_t v0 = vals[i], v1 = vals[i + 1];
+            keys[i] = kn; keys[i + 1] = k0;
+            vals[i] = v1; vals[i + 1] = v0;
         }
-        const uint32_t lo = (uint32_t) __shfl_down((int) (uint32_t) k[0], a, 64);
-        KeyT nb_key = lo;
-        if (sizeof(KeyT) == 8) {
-            const uint32_t hi = (uint32_t) __shfl_down((int) (uint32_t) ((uint64_t) k[0] >> 32), a, 64);
-            nb_key = (KeyT) (((uint64_t) hi << 32) | lo);
-        }
-        if (lane + a >= 64 && i + a < n) nb_key = keys[i + a];
-        k[a] = nb_key;
+        return;
     }
-    if (!in) return;
-    const KeyT h = k[0] >> low_bits;
-    if (i > 0 && (keys[i - 1] >> low_bits) == h) return;   // not the head of a run
-    int L = 1;
+    if (!t3) {   // three elements: stable ranks
+        const uint32_t v0 = vals[i], v1 = vals[i + 1], v2 = vals[i + 2];
+        const int r0 = (kn < k0) + (k2 < k0), r1 = (k0 <= kn) + (k2 < kn), r2 = (k0 <= k2) + (kn <= k2);
+        if (r0 != 0 || r1 != 1) {
+            keys[i + r0] = k0; vals[i + r0] = v0;
+            keys[i + r1] = kn; vals[i + r1] = v1;
+            keys[i + r2] = k2; vals[i + r2] = v2;
+        }
+        return;
+    }
+    // longer: the TIE_REG - 1 keys after the head's own, fetched together
+    KeyT k[TIE_REG];
+    k[0] = k0;
+    k[1] = kn;
 #pragma unroll
-    for (int a = 1; a < TIE_REG; ++a)
+    for (int a = 2; a < TIE_REG; ++a) k[a] = keys[min(i + a, n - 1)];
+    int L = 2;
+#pragma unroll
+    for (int a = 2; a < TIE_REG; ++a)
         if (L == a && i + a < n && (k[a] >> low_bits) == h) L = a + 1;
-    if (L == 1) return;
     if (L == TIE_REG && i + L < n && (keys[i + L] >> low_bits) == h) {   // longer than a thread takes
         long_runs[atomicAdd(long_count, 1u)] = (uint32_t) i;
         return;
@@ -348,7 +379,7 @@ static hipError_t sort_impl(Sim *s)
     // layout of the zeroed block: ghist[8*256] | tickets[8] (+pad to 16) | status[P][rows][256]
     uint32_t *tickets = s->ghist + 8 * 256;
     uint32_t *status = tickets + 16;
-    const int hgrid = std::min(std::max((n + 4095) / 4096, 1), NB_HIST_GRID);  // few blocks: the hot bins take one atomic per block
+    const int hgrid = std::min(std::max((n + 4095) / 4096, 1), NB_HIST_GRID);
     hipLaunchKernelGGL((k_sort_hist<KeyT, NPASS, P0>), dim3(hgrid), dim3(256), 0, s->stream,
                        (const KeyT *) s->keys[0], n, s->ghist);
     int in = 0;

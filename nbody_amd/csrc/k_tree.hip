@@ -22,6 +22,9 @@ void launch_rank_pass(const uint32_t *keys, uint32_t *keys_out, uint32_t *vals_o
                       uint32_t *inv_out, const int32_t *n_dev, int n_max, const uint32_t *hist,
                       uint32_t *status, uint32_t *ticket, uint32_t *err, hipStream_t st);
 
+constexpr int DEPTH_ROW = 32;      // words of a workgroup's depth counts: a 63-bit key has 22 depths
+constexpr int DEPTH_GRID = 2048;   // workgroups of k_depth
+
 template <typename KeyT> struct KeyBits;
 template <> struct KeyBits<uint32_t> { static constexpr int KB = 30; };
 template <> struct KeyBits<uint64_t> { static constexpr int KB = 63; };
@@ -43,70 +46,81 @@ __device__ __forceinline__ int lcp_keys(uint64_t a, uint64_t b)
 // Unique codes: head flags -> tile scan with look-back -> compaction.
 // unique[u], first_pt[u] (index of the first particle carrying the code), first_pt[U] = n.
 // ---------------------------------------------------------------------------
+// Striped: thread t of a tile takes the keys t, t + 256, ... so that every load and (where all
+// flags are set, the usual case) every store has consecutive lanes on consecutive addresses,
+// with nothing staged in LDS.  Order of the output = order of the input: item-major, then
+// wave, then lane; the per-(item, wave) flag counts are scanned by one wave.
+template <int ITEMS>
+__device__ __forceinline__ uint32_t striped_offsets(const unsigned long long (&bal)[ITEMS], uint32_t *s_cnt,
+                                                    uint32_t *s_tot)
+{
+    // s_cnt[ITEMS * 4], filled here with the exclusive prefix of popcount(bal[j]) of wave w at
+    // [j * 4 + w]; returns nothing a caller needs besides *s_tot = flags in the tile.
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) s_cnt[j * 4 + w] = (uint32_t) __popcll(bal[j]);
+    }
+    __syncthreads();
+    if (w == 0) {
+        static_assert(ITEMS * 4 <= 64 || ITEMS * 4 == 128, "one or two values per lane");
+        if (ITEMS * 4 <= 64) {
+            const uint32_t v = lane < ITEMS * 4 ? s_cnt[lane] : 0u;
+            const uint32_t inc = wave_incl_scan_u32(v);
+            if (lane < ITEMS * 4) s_cnt[lane] = inc - v;
+            if (lane == 63) *s_tot = inc;
+        } else {
+            const uint32_t v0 = s_cnt[2 * lane], v1 = s_cnt[2 * lane + 1];
+            const uint32_t inc = wave_incl_scan_u32(v0 + v1);
+            s_cnt[2 * lane] = inc - v0 - v1;
+            s_cnt[2 * lane + 1] = inc - v1;
+            if (lane == 63) *s_tot = inc;
+        }
+    }
+    __syncthreads();
+    return *s_tot;
+}
+
 template <typename KeyT>
 __global__ __launch_bounds__(SCAN_THREADS) void k_unique(const KeyT *__restrict__ sorted, int n,
                                                          KeyT *__restrict__ unique,
                                                          int32_t *__restrict__ first_pt,
                                                          Counts *counts, uint32_t *status,
-                                                         uint32_t *ticket)
+                                                         uint32_t *group_status, uint32_t *ticket)
 {
-    constexpr int NW = SCAN_THREADS / 64;
-    constexpr int PADDED = SCAN_TILE + SCAN_TILE / SCAN_ITEMS;
-    __shared__ uint32_t s_scan[NW + 1];
-    __shared__ uint32_t s_bcast[2];
-    // The tile goes through LDS both ways so that global memory only sees consecutive lanes on
-    // consecutive addresses; every SCAN_ITEMS-th slot is padding (a thread's blocked run of
-    // SCAN_ITEMS keys then starts in a different bank from its neighbours').
-    __shared__ KeyT s_k[PADDED];
-    __shared__ int32_t s_i[SCAN_TILE];
-    auto pad = [](int i) { return i + i / SCAN_ITEMS; };
-    const int tid = threadIdx.x;
+    __shared__ uint32_t s_cnt[SCAN_ITEMS * 4];
+    __shared__ uint32_t s_bcast[3];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) s_bcast[0] = atomicAdd(ticket, 1u);
     __syncthreads();
     const int tile = (int) s_bcast[0];
     const int ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (tile >= ntiles) return;
     const int tile_base = tile * SCAN_TILE;
-    const int base = tile_base + tid * SCAN_ITEMS;
-    for (int j = tid; j < SCAN_TILE; j += SCAN_THREADS) {
-        const int gi = tile_base + j;
-        s_k[pad(j)] = gi < n ? sorted[gi] : 0;
-    }
-    KeyT prev = 0;
-    if (base > 0 && base <= n) prev = sorted[base - 1];
-    __syncthreads();
-
     KeyT k[SCAN_ITEMS];
-    bool f[SCAN_ITEMS];
-    uint32_t cnt = 0;
+    unsigned long long bal[SCAN_ITEMS];
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; ++j) {
-        const int gi = base + j;
-        k[j] = s_k[pad(tid * SCAN_ITEMS + j)];
-        f[j] = gi < n && (gi == 0 || k[j] != prev);
-        prev = k[j];
-        cnt += f[j];
+        const int gi = tile_base + j * SCAN_THREADS + tid;
+        const int ci = min(gi, n - 1);
+        k[j] = sorted[ci];
+        const KeyT prev = sorted[max(ci - 1, 0)];       // (the neighbouring lane's line: a cache hit)
+        bal[j] = __ballot(gi < n && (gi == 0 || k[j] != prev));
     }
-    uint32_t tot;
-    const uint32_t excl = block_excl_scan_u32<NW>(cnt, s_scan, &tot);   // (syncs: s_k is free)
+    const uint32_t tot = striped_offsets<SCAN_ITEMS>(bal, s_cnt, &s_bcast[2]);
     if (tid < 64) {
-        const uint32_t te = lb_exclusive_wave(status, tile, tot, &counts->err);
+        const uint32_t te = lb2_exclusive_wave(status, group_status, tile, tot, &counts->err);
         if (tid == 0) s_bcast[1] = te;
-    }
-    uint32_t lp = excl;
-#pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; ++j) {
-        if (f[j]) {
-            s_k[lp] = k[j];
-            s_i[lp] = base + j;
-            ++lp;
-        }
     }
     __syncthreads();
     const uint32_t tile_excl = s_bcast[1];
-    for (uint32_t j = tid; j < tot; j += SCAN_THREADS) {
-        unique[tile_excl + j] = s_k[j];
-        first_pt[tile_excl + j] = s_i[j];
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        if ((bal[j] >> lane) & 1ull) {
+            const uint32_t pos = tile_excl + s_cnt[j * 4 + w] + (uint32_t) mbcnt(bal[j]);
+            unique[pos] = k[j];
+            first_pt[pos] = tile_base + j * SCAN_THREADS + tid;
+        }
     }
     if (tile == ntiles - 1 && tid == 0) {
         const int U = (int) (tile_excl + tot);
@@ -161,11 +175,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_leaves(const KeyT *__restrict_
                                                          int max_codes, int32_t *__restrict__ lfc,
                                                          KeyT *__restrict__ leaf_key,
                                                          Counts *counts, uint32_t *status,
-                                                         uint32_t *ticket)
+                                                         uint32_t *group_status, uint32_t *ticket)
 {
-    constexpr int NW = SCAN_THREADS / 64;
-    __shared__ uint32_t s_scan[NW + 1];
-    __shared__ uint32_t s_bcast[2];
+    __shared__ uint32_t s_cnt[LEAF_ITEMS * 4];
+    __shared__ uint32_t s_bcast[3];
     __shared__ KeyT s_keys[LEAF_TILE + 2 * LEAF_HALO];
     const int tid = threadIdx.x;
     const int U = counts->U;
@@ -174,7 +187,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_leaves(const KeyT *__restrict_
     const int tile = (int) s_bcast[0];
     const int ntiles = (U + LEAF_TILE - 1) / LEAF_TILE;
     if (tile >= ntiles) return;
-    const int base = tile * LEAF_TILE + tid * LEAF_ITEMS;
     const bool single = U <= max_codes;  // whole set fits one leaf (undefined in the reference)
     // The flag of code i looks at codes i - max_codes .. i + max_codes - 1 in a chain of dependent
     // reads: stage the tile and a halo in LDS so that the chain runs at LDS latency.
@@ -190,30 +202,31 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_leaves(const KeyT *__restrict_
         return (staged && r >= 0 && r < LEAF_TILE + 2 * LEAF_HALO) ? s_keys[r] : unique[j];
     };
 
-    bool f[LEAF_ITEMS];
-    uint32_t cnt = 0;
+    // striped over the tile (thread t takes codes t, t + 256, ...): the lanes of a wave then
+    // probe consecutive LDS words at every step of the search
+    unsigned long long bal[LEAF_ITEMS];
 #pragma unroll
     for (int j = 0; j < LEAF_ITEMS; ++j) {
-        const int i = base + j;
-        f[j] = false;
-        if (i < U) f[j] = single ? (i == 0) : leaf_head_flag<KeyT>(at, i, U, max_codes);
-        cnt += f[j];
+        const int i = tile * LEAF_TILE + j * SCAN_THREADS + tid;
+        bool f = false;
+        if (i < U) f = single ? (i == 0) : leaf_head_flag<KeyT>(at, i, U, max_codes);
+        bal[j] = __ballot(f);
     }
-    uint32_t tot;
-    const uint32_t excl = block_excl_scan_u32<NW>(cnt, s_scan, &tot);
+    const uint32_t tot = striped_offsets<LEAF_ITEMS>(bal, s_cnt, &s_bcast[2]);
     if (tid < 64) {
-        const uint32_t te = lb_exclusive_wave(status, tile, tot, &counts->err);
+        const uint32_t te = lb2_exclusive_wave(status, group_status, tile, tot, &counts->err);
         if (tid == 0) s_bcast[1] = te;
     }
     __syncthreads();
     const uint32_t tile_excl = s_bcast[1];
-    uint32_t pos = tile_excl + excl;
+    const int lane = tid & 63, w = tid >> 6;
 #pragma unroll
     for (int j = 0; j < LEAF_ITEMS; ++j) {
-        if (f[j]) {
-            lfc[pos] = base + j;
-            leaf_key[pos] = at(base + j);
-            ++pos;
+        if ((bal[j] >> lane) & 1ull) {
+            const int i = tile * LEAF_TILE + j * SCAN_THREADS + tid;
+            const uint32_t pos = tile_excl + s_cnt[j * 4 + w] + (uint32_t) mbcnt(bal[j]);
+            lfc[pos] = i;
+            leaf_key[pos] = at(i);
         }
     }
     if (tile == ntiles - 1 && tid == 0) {
@@ -302,9 +315,15 @@ __global__ __launch_bounds__(256) void k_radix(const KeyT *__restrict__ lk, cons
 __global__ __launch_bounds__(256) void k_depth(const Counts *counts,
                                                const int32_t *__restrict__ rt_pd,
                                                uint32_t *__restrict__ depth_key,
-                                               uint32_t *__restrict__ dhist)
+                                               uint32_t *__restrict__ dhist,
+                                               uint32_t *__restrict__ rows, uint32_t *ticket)
 {
+    // The walks are chains of dependent loads: beyond a few million nodes, as many waves as the
+    // chip holds (rows != null).  A workgroup's counts then go to its own row (depths 0..DEPTH_ROW-2 and the "not an octree node" key 255 in
+    // the last word) and the workgroup that finishes last adds the rows up: per-bin global
+    // atomics from a thousand workgroups on two dozen addresses would serialise.
     __shared__ uint32_t h[MAX_DEPTH_BINS];
+    __shared__ uint32_t s_last;
     h[threadIdx.x] = 0;
     __syncthreads();
     const int n_bt = counts->n_bt;
@@ -322,14 +341,48 @@ __global__ __launch_bounds__(256) void k_depth(const Counts *counts,
                 cur = p >> 1;
                 ++guard;
             }
-            key = (uint32_t) min(dsum, 254);
+            key = (uint32_t) min(dsum, DEPTH_ROW - 2);
         }
         depth_key[r] = key;
         atomicAdd(&h[key], 1u);
     }
     __syncthreads();
-    const uint32_t c = h[threadIdx.x];
-    if (c) atomicAdd(&dhist[threadIdx.x], c);
+    if (!rows) {   // few workgroups: one global atomic per workgroup and non-empty bin
+        const uint32_t c = h[threadIdx.x];
+        if (c) atomicAdd(&dhist[threadIdx.x], c);
+        return;
+    }
+    if (threadIdx.x < DEPTH_ROW) {
+        const uint32_t c = threadIdx.x == DEPTH_ROW - 1 ? h[255] : h[threadIdx.x];
+        __hip_atomic_store(&rows[(size_t) blockIdx.x * DEPTH_ROW + threadIdx.x], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0)
+        s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    // DEPTH_ROW bins x 8 partial sums per bin
+    const int bin = threadIdx.x % DEPTH_ROW, part = threadIdx.x / DEPTH_ROW;
+    uint32_t acc = 0;
+    constexpr int PARTS = 256 / DEPTH_ROW;
+    for (int b0 = part; b0 < (int) gridDim.x; b0 += 8 * PARTS) {   // eight loads in flight
+        uint32_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int b = b0 + q * PARTS;
+            v[q] = b < (int) gridDim.x ? __hip_atomic_load(&rows[(size_t) b * DEPTH_ROW + bin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += v[q];
+    }
+    h[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < DEPTH_ROW) {
+        uint32_t t = 0;
+        for (int q = 0; q < 256 / DEPTH_ROW; ++q) t += h[q * DEPTH_ROW + threadIdx.x];
+        dhist[threadIdx.x == DEPTH_ROW - 1 ? 255 : threadIdx.x] = t;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -428,19 +481,22 @@ static hipError_t build_impl(Sim *s)
     const KeyT *sorted = (const KeyT *) s->keys[s->sorted_buf];
     hipLaunchKernelGGL(k_unique<KeyT>, dim3(scan_grid), dim3(SCAN_THREADS), 0, st, sorted, n,
                        (KeyT *) s->unique, s->first_pt, s->counts, s->scan_status,
-                       s->tickets + 0);
+                       s->scan_status + s->max_scan_tiles, s->tickets + 0);
     const int leaf_grid = (n + LEAF_TILE - 1) / LEAF_TILE;
     hipLaunchKernelGGL(k_leaves<KeyT>, dim3(leaf_grid), dim3(SCAN_THREADS), 0, st,
                        (const KeyT *) s->unique, s->p.max_num_codes_per_leaf, s->lfc,
-                       (KeyT *) s->leaf_key, s->counts, s->scan_status + s->max_scan_tiles,
-                       s->tickets + 1);
+                       (KeyT *) s->leaf_key, s->counts, s->scan_status + 2 * (size_t) s->max_scan_tiles,
+                       s->scan_status + 3 * (size_t) s->max_scan_tiles, s->tickets + 1);
     const int node_grid = std::min((n + 255) / 256, 2048);
     hipLaunchKernelGGL(k_radix<KeyT>, dim3(node_grid), dim3(256), 0, st,
                        (const KeyT *) s->leaf_key, s->counts, s->rt_pd, s->rt_level, s->rt_lb,
                        s->rt_le, s->rt_left, s->rt_right);
-    const int depth_grid = std::min((2 * n + 255) / 256, 512);
+    // (every workgroup ends with one same-address ticket atomic, ~15 ns each one after the
+    // other: a large grid pays only where the walks dominate)
+    const bool many = n > (1 << 22);
+    const int depth_grid = std::min((2 * n + 255) / 256, many ? DEPTH_GRID : 512);
     hipLaunchKernelGGL(k_depth, dim3(depth_grid), dim3(256), 0, st, s->counts, s->rt_pd,
-                       s->depth_key, s->dhist);
+                       s->depth_key, s->dhist, many ? s->depth_rows : (uint32_t *) nullptr, s->tickets + 9);
     launch_rank_pass(s->depth_key, s->o_depth, s->bfs, s->octid, &s->counts->n_bt, 2 * n,
                      s->dhist, s->rank_status, s->tickets + 2, &s->counts->err, st);
     hipLaunchKernelGGL(k_emit, dim3(node_grid), dim3(256), 0, st, s->counts, s->p.domain_size,

@@ -148,6 +148,7 @@ struct Sim {
     uint32_t *tickets = nullptr;      // [8]
     uint32_t *scan_status = nullptr;  // [3][max_scan_tiles]
     uint32_t *dhist = nullptr;        // [256] depth histogram
+    uint32_t *depth_rows = nullptr;   // [2048][32] per-workgroup depth counts (k_depth)
     uint32_t *rank_status = nullptr;  // [sort_status_rows(rank_tiles)][256]
     uint32_t *com_counter = nullptr;  // [2n] children-arrived counters
     int max_scan_tiles = 0, rank_tiles = 0;
