@@ -433,6 +433,10 @@ int nbody_traverse_from(nbody_t *sim, nbody_t *sources, int32_t accumulate);
  *   records (x,y,z,m).  A reached inner node that passes the criterion is a leaf of one particle
  *   record, its (centre of mass, mass).  If 32 * nodes + 16 * records > capacity_bytes nothing
  *   is written for that domain (call again with more room).  capacity_bytes: multiple of 16.
+ *   A handle with NBODY_FLAG_FP64 ships doubles: node records of 48 bytes (four doubles, then
+ *   size, first, count, meta), particle records of 32; the frontiers stay float boxes (rounded
+ *   outwards) and the criterion that prunes a copy is evaluated in float either way, as it is
+ *   conservative: what a domain finally takes from a copy is decided by its own traversal.
  * nbody_import_trees_dev: hang `ncopies` such segments (device memory, complete on the handle's
  *   stream; copy r at recv_dev + byte_offset[r] with node_count[r] nodes and record_count[r]
  *   records, host arrays; empty copies allowed) behind the handle's own tree until the next
@@ -480,9 +484,11 @@ typedef struct nbody_comm {
 
 typedef struct nbody_dd nbody_dd_t;
 
-/* Domain decomposition over comm->size processes, this one's particles in `own` (a float
- * handle, created with head-room: num_points >= the most particles the domain will ever hold;
- * the handle stays the caller's, and stays usable for getters).  *comm is copied. */
+/* Domain decomposition over comm->size processes, this one's particles in `own` (a handle of
+ * either precision -- the same on every rank -- created with head-room: num_points >= the most
+ * particles the domain will ever hold; the handle stays the caller's, and stays usable for
+ * getters).  A double handle exchanges doubles: tree copies, migrating particles, sums.
+ * *comm is copied. */
 int nbody_dd_create(nbody_t *own, const nbody_comm *comm, nbody_dd_t **out);
 void nbody_dd_destroy(nbody_dd_t *dd);
 const char *nbody_dd_last_error(nbody_dd_t *dd);
@@ -494,7 +500,7 @@ int nbody_dd_spawn(nbody_dd_t *dd, int kind, int64_t n_total, float p0, float p1
  * migrates the particles: rounds of 4096-bin histograms of key prefixes (12 more bits per
  * round, all-gather; a cut leaves the rounds as soon as a bin edge lies within 0.5 % of a
  * domain's share of its target, and takes the coarsest such cell boundary),
- * one all-to-all of 44-byte particle records (accelerations and ids included, so the step
+ * one all-to-all of 44-byte particle records (88 on double handles; accelerations and ids included, so the step
  * sequence continues unchanged).  Call between steps; synchronises.  NBODY_ERR_CAPACITY if a
  * domain would exceed its handle's num_points. */
 int nbody_dd_rebalance(nbody_dd_t *dd);
@@ -505,12 +511,12 @@ int nbody_dd_step(nbody_dd_t *dd);
  * widened; splitters[size] = 2^bits), and counters of the last step.  Pointers may be NULL. */
 typedef struct nbody_dd_stats {
     int64_t n_local;            /* particles this rank owns                       */
-    int64_t records_sent;       /* particle records (16 bytes) exported in the last step */
+    int64_t records_sent;       /* particle records (16 bytes; double handles 32) exported in the last step */
     int64_t records_received;   /* particle records imported in the last step     */
     int64_t migrated_out;       /* particles given away by the last rebalance     */
     int32_t frontier_records;   /* frontier nodes advertised in the last step     */
     int32_t export_capacity;    /* 16-byte units per destination the export buffer holds */
-    int64_t nodes_sent;         /* node records (32 bytes) exported in the last step */
+    int64_t nodes_sent;         /* node records (32 bytes; double handles 48) exported in the last step */
     int64_t nodes_received;     /* node records imported in the last step            */
 } nbody_dd_stats;
 int nbody_dd_get_stats(nbody_dd_t *dd, nbody_dd_stats *out, uint64_t *splitters);
@@ -529,7 +535,7 @@ typedef struct nbody_dd_phases {
           ms_traversal, ms_total, ms_host_wait, ms_host_total;
     int32_t pad;
     int64_t bytes_frontier;     /* this rank's contribution to the frontier all-gather */
-    int64_t bytes_sent;         /* copies sent in the all-to-all (nodes 32 B, records 16 B) */
+    int64_t bytes_sent;         /* copies sent in the all-to-all (nodes 32 B, records 16 B; doubles 48, 32) */
     int64_t bytes_received;
 } nbody_dd_phases;
 int nbody_dd_set_phase_timing(nbody_dd_t *dd, int32_t on);

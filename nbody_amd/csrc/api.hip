@@ -180,11 +180,9 @@ int alloc_all(Sim *s)
     }
     NB_HIP(s, dalloc(&s->let_boxes, (size_t) LET_REC * LET_MAX_BOXES));
     NB_HIP(s, dalloc(&s->let_counts, (size_t) LET_MAX_BOXES + 8));
-    if (!s->fp64) {
-        NB_HIP(s, dalloc(&s->let_mask, 2 * n));
-        NB_HIP(s, dalloc(&s->let_seg, (size_t) LET_MAX_T + 2));
-        NB_HIP(s, dalloc(&s->let_frontier, (size_t) LET_MAX_T * LET_REC));
-    }
+    NB_HIP(s, dalloc(&s->let_mask, 2 * n));
+    NB_HIP(s, dalloc(&s->let_seg, (size_t) LET_MAX_T + 2));
+    NB_HIP(s, dalloc(&s->let_frontier, (size_t) LET_MAX_T * LET_REC));
     NB_HIP(s, hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming));
     const size_t red_bytes = reduce_scratch_bytes(REDUCE_MAX_BLOCKS, 3);
     NB_HIP(s, hipMalloc((void **) &s->red_scratch, red_bytes));
@@ -579,27 +577,58 @@ namespace nb {
 
 int install_particles_dev(Sim *s, int n)
 {
-    if (s->fp64) return fail(s, NBODY_ERR_STATE, "install_particles: float handles only");
     if (n < 1 || n > s->cap) return fail(s, NBODY_ERR_CAPACITY, "install_particles: count outside [1, num_points]");
     s->n = n;
     s->uniform_mass = 0.f;   // particles of other ranks: their masses are not known here
     NB_HIP(s, hipMemsetAsync(s->counts, 0, sizeof(Counts), s->stream));
-    NB_HIP(s, launch_morton_only(s));
+    NB_HIP(s, s->fp64 ? launch64_morton_only(s) : launch_morton_only(s));
     int rc = build_after_encode(s, true);   // permutes x,y,z,m,v,vh,id: the accelerations ride in vh
     if (rc) return rc;
     const int c = s->cur;
-    const size_t b = (size_t) n * sizeof(float);
-    NB_HIP(s, hipMemcpyAsync(s->ax, s->vhx[c], b, hipMemcpyDeviceToDevice, s->stream));
-    NB_HIP(s, hipMemcpyAsync(s->ay, s->vhy[c], b, hipMemcpyDeviceToDevice, s->stream));
-    NB_HIP(s, hipMemcpyAsync(s->az, s->vhz[c], b, hipMemcpyDeviceToDevice, s->stream));
+    if (s->fp64) {
+        const size_t b = (size_t) n * sizeof(double);
+        NB_HIP(s, hipMemcpyAsync(s->d.ax, s->d.vhx[c], b, hipMemcpyDeviceToDevice, s->stream));
+        NB_HIP(s, hipMemcpyAsync(s->d.ay, s->d.vhy[c], b, hipMemcpyDeviceToDevice, s->stream));
+        NB_HIP(s, hipMemcpyAsync(s->d.az, s->d.vhz[c], b, hipMemcpyDeviceToDevice, s->stream));
+    } else {
+        const size_t b = (size_t) n * sizeof(float);
+        NB_HIP(s, hipMemcpyAsync(s->ax, s->vhx[c], b, hipMemcpyDeviceToDevice, s->stream));
+        NB_HIP(s, hipMemcpyAsync(s->ay, s->vhy[c], b, hipMemcpyDeviceToDevice, s->stream));
+        NB_HIP(s, hipMemcpyAsync(s->az, s->vhz[c], b, hipMemcpyDeviceToDevice, s->stream));
+    }
     NB_HIP(s, launch_build(s));
-    NB_HIP(s, launch_com(s));
-    NB_HIP(s, launch_export_view(s));
+    NB_HIP(s, s->fp64 ? launch64_com(s) : launch_com(s));
+    NB_HIP(s, s->fp64 ? launch64_export_view(s) : launch_export_view(s));
     s->spawned = true;
     s->pending_vel = false;
     s->ev_pending = 0;
     s->t_acc = nbody_timings{};
     return NBODY_OK;
+}
+
+// Particles [first, first + count) of a sampled set of n_total, drawn in the handle's precision,
+// ids = index in the whole set.
+template <typename R>
+static int spawn_range_r(Sim *s, int kind, long long first, int count, long long n_total, float p0, float p1)
+{
+    const size_t n = (size_t) count;
+    std::vector<R> x(n), y(n), z(n), vx(n), vy(n), vz(n), m(n);
+    std::vector<uint32_t> id(n);
+    int rc = sample_ic<R>(kind, count, s->p.seed, s->p.domain_size, s->p.gravity, p0, p1, x.data(), y.data(),
+                          z.data(), vx.data(), vy.data(), vz.data(), m.data(), first, n_total);
+    if (rc) return rc;
+    for (size_t i = 0; i < n; ++i) id[i] = (uint32_t) (first + (long long) i);
+    if (s->p.num_steps_validator > 0 && count != s->cap)
+        return fail(s, NBODY_ERR_STATE, "a handle with a validator keeps num_points particles");
+    return set_particles<R>(s, count, x.data(), y.data(), z.data(), vx.data(), vy.data(), vz.data(), m.data(),
+                            (const R *) nullptr, (const R *) nullptr, (const R *) nullptr, id.data());
+}
+
+int spawn_range(Sim *s, int kind, long long first, int count, long long n_total, float p0, float p1)
+{
+    if (count < 1 || count > s->cap) return fail(s, NBODY_ERR_CAPACITY, "spawn_range: count outside [1, num_points]");
+    return s->fp64 ? spawn_range_r<double>(s, kind, first, count, n_total, p0, p1)
+                   : spawn_range_r<float>(s, kind, first, count, n_total, p0, p1);
 }
 
 int sample_ic_range(int kind, long long first, int count, long long n_total, uint64_t seed, float domain,
@@ -1235,7 +1264,6 @@ int nbody_let_export(nbody_t *h, const float *boxes, int32_t nboxes, float *out_
 int nbody_let_frontier_dev(nbody_t *h, float *records_dev, int32_t max_records)
 {
     NB_ENTER(h);
-    NB_FLOAT_ONLY(s, "nbody_let_frontier_dev");
     if (!records_dev || max_records < 1 || max_records > LET_MAX_T)
         return fail(s, NBODY_ERR_INVALID, "let_frontier: max_records outside [1, 32]");
     if (!s->spawned || s->n < 1) return fail(s, NBODY_ERR_STATE, "let_frontier of an empty handle");
@@ -1346,40 +1374,54 @@ int nbody_traverse_from(nbody_t *h, nbody_t *sources, int32_t accumulate)
     return NBODY_OK;
 }
 
+}  // extern "C"
+
 // Room for imported tree copies behind the own tree: node arrays from index 2 * cap on, particle
 // arrays from imp_part_base(s) on.  Growing re-allocates the four arrays and keeps their contents.
 static int imp_part_base(const Sim *s) { return (s->cap + 3) & ~3; }
+
+template <typename R4>
+static int grow_import_arrays(Sim *s, R4 *&nodeA, R4 *&posm, int ncap, int pcap)
+{
+    const size_t own_nodes = 2 * (size_t) s->cap, pb = (size_t) imp_part_base(s);
+    R4 *nA = nullptr, *pm = nullptr;
+    NodeB *nB = nullptr;
+    NB_HIP(s, dalloc(&nA, own_nodes + ncap)); NB_HIP(s, dalloc(&nB, own_nodes + ncap));
+    NB_HIP(s, dalloc(&pm, pb + pcap));
+    NB_HIP(s, hipMemcpyAsync(nA, nodeA, (own_nodes + s->imp_node_cap) * sizeof(R4), hipMemcpyDeviceToDevice, s->stream));
+    NB_HIP(s, hipMemcpyAsync(nB, s->nodeB, (own_nodes + s->imp_node_cap) * sizeof(NodeB), hipMemcpyDeviceToDevice, s->stream));
+    const size_t old_parts = s->imp_part_cap ? pb + (size_t) s->imp_part_cap : (size_t) s->cap;
+    NB_HIP(s, hipMemcpyAsync(pm, posm, old_parts * sizeof(R4), hipMemcpyDeviceToDevice, s->stream));
+    float *pm2 = nullptr;
+    if (!s->fp64) {   // the pair-interleaved copy of the float traversal
+        const size_t posm2_floats = 16 * ((pb + (size_t) pcap + 3) / 4);
+        NB_HIP(s, dalloc(&pm2, posm2_floats));
+        NB_HIP(s, hipMemsetAsync(pm2, 0, posm2_floats * 4, s->stream));
+        NB_HIP(s, hipMemcpyAsync(pm2, s->posm2, 16 * ((old_parts + 3) / 4) * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+    }
+    NB_HIP(s, hipStreamSynchronize(s->stream));
+    NB_HIP(s, hipFree(nodeA)); NB_HIP(s, hipFree(s->nodeB)); NB_HIP(s, hipFree(posm));
+    if (!s->fp64) { NB_HIP(s, hipFree(s->posm2)); s->posm2 = pm2; }
+    nodeA = nA; s->nodeB = nB; posm = pm;
+    s->imp_node_cap = ncap; s->imp_part_cap = pcap;
+    return NBODY_OK;
+}
 
 static int ensure_import_capacity(Sim *s, int nodes, int parts)
 {
     if (nodes <= s->imp_node_cap && parts <= s->imp_part_cap) return NBODY_OK;
     const int ncap = std::max(s->imp_node_cap, nodes + nodes / 4 + 1024);
     const int pcap = std::max(s->imp_part_cap, parts + parts / 4 + 1024);
-    const size_t own_nodes = 2 * (size_t) s->cap, pb = (size_t) imp_part_base(s);
-    Float4 *nA = nullptr, *pm = nullptr;
-    NodeB *nB = nullptr;
-    float *pm2 = nullptr;
-    const size_t posm2_floats = 16 * ((pb + (size_t) pcap + 3) / 4);
-    NB_HIP(s, dalloc(&nA, own_nodes + ncap)); NB_HIP(s, dalloc(&nB, own_nodes + ncap));
-    NB_HIP(s, dalloc(&pm, pb + pcap)); NB_HIP(s, dalloc(&pm2, posm2_floats));
-    NB_HIP(s, hipMemsetAsync(pm2, 0, posm2_floats * 4, s->stream));
-    NB_HIP(s, hipMemcpyAsync(nA, s->nodeA, (own_nodes + s->imp_node_cap) * sizeof(Float4), hipMemcpyDeviceToDevice, s->stream));
-    NB_HIP(s, hipMemcpyAsync(nB, s->nodeB, (own_nodes + s->imp_node_cap) * sizeof(NodeB), hipMemcpyDeviceToDevice, s->stream));
-    const size_t old_parts = s->imp_part_cap ? pb + (size_t) s->imp_part_cap : (size_t) s->cap;
-    NB_HIP(s, hipMemcpyAsync(pm, s->posm, old_parts * sizeof(Float4), hipMemcpyDeviceToDevice, s->stream));
-    NB_HIP(s, hipMemcpyAsync(pm2, s->posm2, 16 * ((old_parts + 3) / 4) * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
-    NB_HIP(s, hipStreamSynchronize(s->stream));
-    NB_HIP(s, hipFree(s->nodeA)); NB_HIP(s, hipFree(s->nodeB)); NB_HIP(s, hipFree(s->posm)); NB_HIP(s, hipFree(s->posm2));
-    s->nodeA = nA; s->nodeB = nB; s->posm = pm; s->posm2 = pm2;
-    s->imp_node_cap = ncap; s->imp_part_cap = pcap;
-    return NBODY_OK;
+    return s->fp64 ? grow_import_arrays<Double4>(s, s->d.nodeA, s->d.posm, ncap, pcap)
+                   : grow_import_arrays<Float4>(s, s->nodeA, s->posm, ncap, pcap);
 }
+
+extern "C" {
 
 int nbody_let_export_tree_dev(nbody_t *h, const float *frontiers_dev, int32_t ndomains, int32_t records_per_domain,
                               int32_t skip_domain, void *out_dev, size_t capacity_bytes, int32_t *counts_dev)
 {
     NB_ENTER(h);
-    NB_FLOAT_ONLY(s, "nbody_let_export_tree_dev");
     if (!frontiers_dev || !out_dev || !counts_dev || ndomains < 1 || ndomains > LET_MAX_BOXES ||
         records_per_domain < 1 || records_per_domain > LET_MAX_T || (capacity_bytes & 15))
         return fail(s, NBODY_ERR_INVALID, "let_export_tree_dev: bad arguments");
@@ -1402,7 +1444,6 @@ int nbody_import_trees_dev(nbody_t *h, const void *recv_dev, int32_t ncopies, co
                            const int32_t *node_count, const int32_t *record_count)
 {
     NB_ENTER(h);
-    NB_FLOAT_ONLY(s, "nbody_import_trees_dev");
     if (ncopies < 0 || ncopies > LET_MAX_BOXES || (ncopies > 0 && (!recv_dev || !byte_offset || !node_count || !record_count)))
         return fail(s, NBODY_ERR_INVALID, "import_trees: bad arguments");
     if (!s->spawned) return fail(s, NBODY_ERR_STATE, "import_trees before spawn/set_state");
@@ -1417,7 +1458,8 @@ int nbody_import_trees_dev(nbody_t *h, const void *recv_dev, int32_t ncopies, co
         nodes += node_count[r];
         parts += record_count[r];
     }
-    if (nodes + parts > 0x7fffffffLL || 2LL * s->cap + nodes > 0x7fffffffLL)
+    // (the double traversal keeps a flag in bit 30 of its stack entries)
+    if (nodes + parts > 0x7fffffffLL || 2LL * s->cap + nodes > (s->fp64 ? 0x3fffffffLL : 0x7fffffffLL))
         return fail(s, NBODY_ERR_CAPACITY, "import_trees: too many records");
     int rc = ensure_import_capacity(s, (int) nodes, (int) parts);
     if (rc) return rc;
@@ -1450,7 +1492,6 @@ int nbody_import_trees_dev(nbody_t *h, const void *recv_dev, int32_t ncopies, co
 
 int nb::traverse_forest(Sim *s, int what, int group_begin, int group_end, bool kick)
 {
-    if (s->fp64) return fail(s, NBODY_ERR_STATE, "nbody_traverse_forest: float handles only");
     if (!s->spawned) return fail(s, NBODY_ERR_STATE, "traverse_forest before spawn/set_state");
     const int ngroups = (s->n + s->group - 1) / s->group;
     if (group_end < 0) { group_begin = 0; group_end = ngroups; }
@@ -1463,7 +1504,10 @@ int nb::traverse_forest(Sim *s, int what, int group_begin, int group_end, bool k
     if (k < 2) NB_HIP(s, hipEventRecord(s->ev[slot][EV_TF0_BEGIN + 2 * k], s->stream));
     const int g0 = s->trav_g0, g1 = s->trav_g1;
     s->trav_g0 = group_begin; s->trav_g1 = group_end;
-    hipError_t e = launch_traverse_forest(s, what, kick);
+    // (double handles have no fused kick: theirs is its own launch, over every particle, and
+    // only a pass that covers all of them may ask for it)
+    hipError_t e = s->fp64 ? launch64_traverse_forest(s, what) : launch_traverse_forest(s, what, kick);
+    if (e == hipSuccess && s->fp64 && kick) e = launch64_vel_kick(s);
     s->trav_g0 = g0; s->trav_g1 = g1;
     NB_HIP(s, e);
     if (k < 2) NB_HIP(s, hipEventRecord(s->ev[slot][EV_TF0_END + 2 * k], s->stream));

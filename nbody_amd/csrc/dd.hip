@@ -33,7 +33,13 @@ namespace {
 
 constexpr int DD_BINS = 4096;        // histogram bins per refinement round (12 key bits)
 constexpr int DD_BIN_BITS = 12;
-constexpr int MIG_BYTES = 44;        // migrating particle record (k_pack_particles)
+// migrating particle record (k_pack_particles): eleven words of the handle's precision
+inline size_t mig_bytes(const Sim *s) { return s->fp64 ? 88 : 44; }
+// a tree copy's records: node = (centre of mass, mass) + NodeB, particle = (position, mass)
+inline size_t copy_bytes(const Sim *s, int64_t nodes, int64_t parts)
+{
+    return s->fp64 ? (size_t) nodes * 48 + (size_t) parts * 32 : (size_t) nodes * 32 + (size_t) parts * 16;
+}
 constexpr double DD_SLACK = 0.005;   // a cut may miss its target by this share of a domain
 
 struct DD {
@@ -61,7 +67,7 @@ struct DD {
     int32_t *lb_dev = nullptr;       // their positions in the sorted keys
     uint32_t *hist_dev = nullptr, *hist_all = nullptr;
     size_t hist_words = 0;
-    float *mig_send = nullptr, *mig_recv = nullptr;
+    unsigned char *mig_send = nullptr, *mig_recv = nullptr;
     size_t mig_send_cap = 0, mig_recv_cap = 0;
     std::vector<uint64_t> splitters;
     nbody_dd_stats stats{};
@@ -260,7 +266,6 @@ int nbody_dd_create(nbody_t *own, const nbody_comm *comm, nbody_dd_t **out)
         return NBODY_ERR_INVALID;
     *out = nullptr;
     Sim *s = reinterpret_cast<Sim *>(own);
-    if (s->fp64) return NBODY_ERR_STATE;
     DD *d = new (std::nothrow) DD();
     if (!d) return NBODY_ERR_INVALID;
     d->own = s;
@@ -358,7 +363,8 @@ int nbody_dd_step(nbody_dd_t *h)
     DD_HIP(d, mark(1));
     if (W == 1) {
         if (have) {
-            DD_NB(d, nbody_traverse_from(H(s), H(s), 0));
+            if (s->fp64) DD_NB(d, nbody_traverse_forest(H(s), 0, 0, -1));
+            else DD_NB(d, nbody_traverse_from(H(s), H(s), 0));
             DD_NB(d, nbody_finish_step(H(s)));
         }
         d->stats.records_sent = d->stats.records_received = 0;
@@ -391,7 +397,7 @@ int nbody_dd_step(nbody_dd_t *h)
     d->host_wait_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wait_t0).count();
     size_t need = 0;
     for (int r = 0; r < W; ++r)
-        need = std::max(need, (size_t) d->cnt_host[2 * r] * 32 + (size_t) d->cnt_host[2 * r + 1] * 16);
+        need = std::max(need, copy_bytes(s, d->cnt_host[2 * r], d->cnt_host[2 * r + 1]));
     if (need > d->exp_cap) {
         // A copy is larger than a segment of the buffer (first steps, or the domains have
         // changed).  The sizes are the true ones either way and the peers have them already,
@@ -409,9 +415,9 @@ int nbody_dd_step(nbody_dd_t *h)
         const bool other = r != me;
         const int32_t snn = other ? d->cnt_host[2 * r] : 0, snr = other ? d->cnt_host[2 * r + 1] : 0;
         const int32_t rnn = other ? d->cnt_host[2 * W + 2 * r] : 0, rnr = other ? d->cnt_host[2 * W + 2 * r + 1] : 0;
-        sb[r] = (size_t) snn * 32 + (size_t) snr * 16;
+        sb[r] = copy_bytes(s, snn, snr);
         so[r] = (size_t) r * d->exp_cap;
-        rb[r] = (size_t) rnn * 32 + (size_t) rnr * 16;
+        rb[r] = copy_bytes(s, rnn, rnr);
         ro[r] = total_recv;
         if (other) { off.push_back(total_recv); cn.push_back(rnn); cr.push_back(rnr); }
         total_recv += rb[r];
@@ -444,16 +450,19 @@ int nbody_dd_step(nbody_dd_t *h)
         DD_NB(d, nbody_import_trees_dev(H(s), d->recv_buf, (int32_t) cn.size(), off.data(), cn.data(), cr.data()));
         DD_HIP(d, mark(7));
         // both passes are the last word on their groups' accelerations: the kick rides along
-        DD_NB(d, traverse_forest(s, 1, early, ngroups, true));          // own tree and copies, one walk
+        // (float handles; a double handle's kick is a launch of its own after the walks)
+        const bool fuse = !s->fp64;
+        DD_NB(d, traverse_forest(s, 1, early, ngroups, fuse));          // own tree and copies, one walk
         if (early > 0) {
-            if (s->imp_nroots > 0) DD_NB(d, traverse_forest(s, 2, 0, early, true));   // the copies alone, added
-            else {   // nobody sent anything: the first groups still want their kick
+            if (s->imp_nroots > 0) DD_NB(d, traverse_forest(s, 2, 0, early, fuse));   // the copies alone, added
+            else if (fuse) {   // nobody sent anything: the first groups still want their kick
                 const int c = s->cur;
                 DD_HIP(d, launch_vel_kick_raw(std::min(early * s->group, s->n), s->p.dt, 1.0f - s->p.velocity_dampening,
                                               s->vhx[c], s->vhy[c], s->vhz[c], s->ax, s->ay, s->az, s->vx[c], s->vy[c],
                                               s->vz[c], s->stream));
             }
         }
+        if (!fuse) DD_HIP(d, launch64_vel_kick(s));
         s->pending_vel = false;
     } else {
         DD_HIP(d, mark(7));
@@ -590,13 +599,14 @@ int nbody_dd_rebalance(nbody_dd_t *h)
     DD_HIP(d, hipMemcpyAsync(mat.data(), d->hist_all, mat.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     DD_HIP(d, hipStreamSynchronize(s->stream));
     size_t total_recv = 0;
+    const size_t mb = mig_bytes(s);
     std::vector<size_t> sb(W), so(W), rb(W), ro(W);
     for (int r = 0; r < W; ++r) {
-        sb[r] = (size_t) sc[r] * MIG_BYTES;
-        so[r] = (size_t) lb[r] * MIG_BYTES;
+        sb[r] = (size_t) sc[r] * mb;
+        so[r] = (size_t) lb[r] * mb;
         const size_t cnt = mat[(size_t) r * W + me];
-        rb[r] = cnt * MIG_BYTES;
-        ro[r] = total_recv * MIG_BYTES;
+        rb[r] = cnt * mb;
+        ro[r] = total_recv * mb;
         total_recv += cnt;
     }
     // (a domain that would overflow its handle still takes part in the exchange, into a buffer
@@ -605,7 +615,7 @@ int nbody_dd_rebalance(nbody_dd_t *h)
         if (d->mig_send) DD_HIP(d, hipFree(d->mig_send));
         d->mig_send = nullptr;
         d->mig_send_cap = 0;
-        DD_HIP(d, hipMalloc((void **) &d->mig_send, std::max<size_t>((size_t) s->cap, n_local) * MIG_BYTES));
+        DD_HIP(d, hipMalloc((void **) &d->mig_send, std::max<size_t>((size_t) s->cap, n_local) * mb));
         d->mig_send_cap = std::max<size_t>((size_t) s->cap, n_local);
     }
     if (!d->mig_recv || total_recv > d->mig_recv_cap) {
@@ -613,7 +623,7 @@ int nbody_dd_rebalance(nbody_dd_t *h)
         d->mig_recv = nullptr;
         d->mig_recv_cap = 0;
         const size_t cap = std::max<size_t>((size_t) s->cap, total_recv);
-        DD_HIP(d, hipMalloc((void **) &d->mig_recv, cap * MIG_BYTES));
+        DD_HIP(d, hipMalloc((void **) &d->mig_recv, cap * mb));
         d->mig_recv_cap = cap;
     }
     if (n_local > 0) DD_HIP(d, launch_pack_particles(s, d->mig_send));
@@ -652,14 +662,9 @@ int nbody_dd_spawn(nbody_dd_t *h, int kind, int64_t n_total, float p0, float p1)
     const int64_t first = n_total * me / W, last = n_total * (me + 1) / W;
     const int count = (int) (last - first);
     if (count > s->cap) return dfail(d, NBODY_ERR_CAPACITY, "spawn: num_points is smaller than n_total / ranks");
-    std::vector<float> x(count), y(count), z(count), vx(count), vy(count), vz(count), m(count);
-    std::vector<uint32_t> id(count);
-    int rc = sample_ic_range(kind, first, count, n_total, s->p.seed, s->p.domain_size, s->p.gravity, p0, p1,
-                             x.data(), y.data(), z.data(), vx.data(), vy.data(), vz.data(), m.data());
-    if (rc) return dfail(d, rc, "spawn: unknown initial condition kind");
-    for (int i = 0; i < count; ++i) id[i] = (uint32_t) (first + i);
-    DD_NB(d, nbody_set_particles(H(s), count, x.data(), y.data(), z.data(), vx.data(), vy.data(), vz.data(),
-                                 m.data(), nullptr, nullptr, nullptr, id.data()));
+    int rc = spawn_range(s, kind, first, count, n_total, p0, p1);   // samples in the handle's precision
+    if (rc == NBODY_ERR_INVALID) return dfail(d, rc, "spawn: unknown initial condition kind");
+    if (rc) return dfail(d, rc, std::string("spawn: ") + nbody_last_error(H(s)));
     DD_NB(d, nbody_set_traversal_range(H(s), 0, 0));
     return nbody_dd_rebalance(h);
 }

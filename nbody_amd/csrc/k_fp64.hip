@@ -185,6 +185,7 @@ constexpr int T64_WAVES = 4;
 constexpr int T64_STACK = 1024;
 constexpr int T64_RESERVE = 7 * 24;
 constexpr int T64_RING = 128;
+constexpr int T64_DIRECT = 1 << 30;   // stack entry flag: take the node without a test
 
 struct alignas(16) T64Lds {
     Double4 ring[T64_RING];
@@ -199,8 +200,15 @@ __global__ __launch_bounds__(64 * T64_WAVES) void k64_traverse(
     int n, int g0, int ngroups, const Double4 *__restrict__ posm, const Double4 *__restrict__ nodeA,
     const NodeB *__restrict__ nodeB, double theta2, double eps2, double gravity, double dinit,
     double *__restrict__ ax, double *__restrict__ ay, double *__restrict__ az,
-    double *__restrict__ pot, uint32_t *__restrict__ list_len, uint32_t *err, int stack_cap)
+    double *__restrict__ pot, uint32_t *__restrict__ list_len, uint32_t *err, int stack_cap,
+    const int32_t *__restrict__ roots, int nroots, int acc_flag)
 {
+    // Stack entries: node id, with T64_DIRECT set when the node is to be taken without a test:
+    // a leaf its parent marks in the child mask.  In the handle's own tree every leaf child is
+    // marked (a leaf is always evaluated directly, as in the reference); in the pruned copies of
+    // other domains' trees (nroots > 0) only the children that pass for the whole domain are,
+    // and an unmarked leaf is tested like an inner node.  acc_flag: bit 0 = add to ax/ay/az,
+    // bit 2 = leave the own root out.
     __shared__ T64Lds lds[T64_WAVES];
     const int lane = (int) threadIdx.x & 63, w = (int) threadIdx.x >> 6;
     if ((int) blockIdx.x * T64_WAVES + w >= ngroups) return;   // whole wave; no workgroup barrier here
@@ -215,8 +223,16 @@ __global__ __launch_bounds__(64 * T64_WAVES) void k64_traverse(
     const bool active = bl < nb;
     const Double4 me = posm[active ? b0 + bl : b0];
     L.bx[lane] = me.x; L.by[lane] = me.y; L.bz[lane] = me.z;
-    if (lane == 0) L.stack[0] = 0;
-    int sp = 1;
+    int sp = 0;
+    if (!(acc_flag & 4)) {
+        if (lane == 0) L.stack[0] = (nodeB[0].meta & NODE_LEAF) ? T64_DIRECT : 0;
+        sp = 1;
+    }
+    for (int r0 = 0; r0 < nroots; r0 += 64) {   // nroots <= LET_MAX_BOXES < stack size
+        const int k = min(64, nroots - r0);
+        if (lane < k) L.stack[sp + lane] = roots[r0 + lane];
+        sp += k;
+    }
     __builtin_amdgcn_wave_barrier();
 
     double fx = 0.0, fy = 0.0, fz = 0.0, ps = 0.0;
@@ -276,7 +292,8 @@ __global__ __launch_bounds__(64 * T64_WAVES) void k64_traverse(
         }
         const int fit = (stack_cap - T64_RESERVE - sp) / 7;
         const int p = fit >= 1 ? min(min(64, sp), fit) : 1;
-        const int node = lane < p ? L.stack[sp - p + lane] : -1;
+        const int entry = lane < p ? L.stack[sp - p + lane] : -1;
+        const int node = entry < 0 ? -1 : (entry & ~T64_DIRECT);
         sp -= p;
         __builtin_amdgcn_wave_barrier();
 
@@ -286,7 +303,7 @@ __global__ __launch_bounds__(64 * T64_WAVES) void k64_traverse(
         if (node >= 0) {
             B = nodeB[node];
             is_leaf = (B.meta & NODE_LEAF) != 0u;
-            if (!is_leaf) {
+            if (!(entry & T64_DIRECT)) {
                 A = nodeA[node];
                 double dmin = dinit;
                 for (int j = 0; j < nb; ++j) {
@@ -296,7 +313,8 @@ __global__ __launch_bounds__(64 * T64_WAVES) void k64_traverse(
                 }
                 const double sz = (double) B.size;
                 accept = sz * sz / dmin < theta2;
-                open = !accept;
+                open = !accept && !is_leaf;
+                is_leaf = is_leaf && !accept;   // a tested leaf that fails is taken particle by particle
             }
         }
         total += (uint32_t) __popcll(__ballot(accept));
@@ -307,7 +325,8 @@ __global__ __launch_bounds__(64 * T64_WAVES) void k64_traverse(
             const uint32_t incl = wave_incl_scan_u32(nc);
             const int tot = (int) __shfl(incl, 63, 64);
             const int at = sp + (int) (incl - nc);
-            for (uint32_t c = 0; c < nc; ++c) L.stack[at + (int) c] = B.first + (int) c;
+            for (uint32_t c = 0; c < nc; ++c)
+                L.stack[at + (int) c] = (B.first + (int) c) | (((B.meta >> c) & 1u) ? T64_DIRECT : 0);
             sp += tot;
         }
         {   // particles of the popped leaves, 64 at a time in leaf order
@@ -343,6 +362,8 @@ __global__ __launch_bounds__(64 * T64_WAVES) void k64_traverse(
         const int b = b0 + bl;
         if (POT) {
             pot[b] = ps - me.w * rsq64(eps2);   // the body's own term, met exactly once
+        } else if (acc_flag & 1) {
+            ax[b] += gravity * fx; ay[b] += gravity * fy; az[b] += gravity * fz;
         } else {
             ax[b] = gravity * fx; ay[b] = gravity * fy; az[b] = gravity * fz;
         }
@@ -491,7 +512,9 @@ hipError_t launch64_com(Sim *s)
     return hipGetLastError();
 }
 
-hipError_t launch64_traverse(Sim *s, bool potential)
+// what: 0 = the own tree, 1 = own tree and imported copies in one walk, 2 = the copies alone,
+// added to the accelerations (see launch_traverse_forest)
+static hipError_t traverse64_impl(Sim *s, bool potential, int what)
 {
     State64 &d = s->d;
     const int all = (s->n + s->group - 1) / s->group;
@@ -506,16 +529,23 @@ hipError_t launch64_traverse(Sim *s, bool potential)
     const double dom = (double) s->p.domain_size;
     // test aid: 32 usable entries make single-node depth-first rounds the common case
     const int stack_cap = (s->p.flags & NBODY_FLAG_DEBUG_SMALL_STACK) ? T64_RESERVE + 32 : T64_STACK;
+    const int32_t *roots = what ? s->imp_roots : nullptr;
+    const int nroots = what ? s->imp_nroots : 0;
+    const int acc_flag = what == 2 ? 5 : 0;
 #define NB_T64(GG, PP)                                                                           \
     hipLaunchKernelGGL((k64_traverse<GG, PP>), dim3(grid), dim3(64 * T64_WAVES), 0, s->stream,    \
                        s->n, g0, ngroups, d.posm, d.nodeA, s->nodeB, theta * theta, eps * eps,    \
                        (double) s->p.gravity, dom * dom * 3.0, d.ax, d.ay, d.az, d.pot,           \
-                       s->list_len, &s->counts->err, stack_cap)
+                       s->list_len, &s->counts->err, stack_cap, roots, nroots, acc_flag)
     if (s->group == 64) { if (potential) NB_T64(64, true); else NB_T64(64, false); }
     else                { if (potential) NB_T64(32, true); else NB_T64(32, false); }
 #undef NB_T64
     return hipGetLastError();
 }
+
+hipError_t launch64_traverse(Sim *s, bool potential) { return traverse64_impl(s, potential, 0); }
+
+hipError_t launch64_traverse_forest(Sim *s, int what) { return traverse64_impl(s, false, what); }
 
 hipError_t launch64_vel_kick(Sim *s)
 {

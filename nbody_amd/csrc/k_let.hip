@@ -42,6 +42,14 @@ __global__ __launch_bounds__(256) void k_bbox(int n, const Float4 *__restrict__ 
     }
 }
 
+// (x,y,z,w) of either precision as floats; bounds of a coordinate as floats that enclose it
+__device__ __forceinline__ Float4 narrow4(const Float4 v) { return v; }
+__device__ __forceinline__ Float4 narrow4(const Double4 v) { return Float4{(float) v.x, (float) v.y, (float) v.z, (float) v.w}; }
+__device__ __forceinline__ float bound_lo(float v) { return v; }
+__device__ __forceinline__ float bound_hi(float v) { return v; }
+__device__ __forceinline__ float bound_lo(double v) { return __double2float_rd(v); }
+__device__ __forceinline__ float bound_hi(double v) { return __double2float_ru(v); }
+
 __device__ __forceinline__ float box_dist_sq(const float *__restrict__ bx, float cx, float cy,
                                              float cz)
 {
@@ -63,9 +71,10 @@ __device__ __forceinline__ float box_dist_sq(const float *__restrict__ bx, float
 // Unused records are empty boxes (lo = 3e38, hi = 0), which are farther than anything.
 // One workgroup of 256 threads; T <= LET_MAX_T = 32.
 // ---------------------------------------------------------------------------
+template <typename R4>
 __global__ __launch_bounds__(256) void k_frontier_select(
     const Counts *counts, int n, int T, const NodeB *__restrict__ nodeB,
-    const Float4 *__restrict__ nodeA, const int32_t *__restrict__ o_pb,
+    const R4 *__restrict__ nodeA, const int32_t *__restrict__ o_pb,
     const int32_t *__restrict__ o_pe, float *__restrict__ rec, int32_t *__restrict__ seg)
 {
     __shared__ uint32_t s_scan[5];
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(256) void k_frontier_select(
             for (int j = 0; j < F; ++j) slot += s_first[j] < s_first[tid];
             r = rec + (size_t) slot * LET_REC;
             const int o = s_node[tid];
-            const Float4 A = nodeA[o];
+            const Float4 A = narrow4(nodeA[o]);
             r[0] = r[1] = r[2] = 3.0e38f;
             r[3] = r[4] = r[5] = 0.f;
             r[6] = A.x; r[7] = A.y; r[8] = A.z; r[9] = A.w;
@@ -136,7 +145,8 @@ __global__ __launch_bounds__(256) void k_frontier_select(
 // binary search over the <= T first-particle indices; a wave whose 64 particles share a node
 // (nearly all do) reduces first and issues one atomic per bound.  Positions are >= 0, so the
 // order of the floats is the order of their bit patterns.
-__global__ __launch_bounds__(256) void k_frontier_bbox(int n, const Float4 *__restrict__ posm,
+template <typename R4>
+__global__ __launch_bounds__(256) void k_frontier_bbox(int n, const R4 *__restrict__ posm,
                                                        const int32_t *__restrict__ seg,
                                                        float *__restrict__ rec)
 {
@@ -153,10 +163,11 @@ __global__ __launch_bounds__(256) void k_frontier_bbox(int n, const Float4 *__re
         const int i = base + tid;
         const bool valid = i < n;
         int sg = 0;
-        uint32_t v[3] = {0, 0, 0};
+        uint32_t v[3] = {0, 0, 0}, u[3] = {0, 0, 0};   // lower and upper float bounds of the coordinates
         if (valid) {
-            const Float4 p = posm[i];
-            v[0] = __float_as_uint(p.x); v[1] = __float_as_uint(p.y); v[2] = __float_as_uint(p.z);
+            const R4 p = posm[i];
+            v[0] = __float_as_uint(bound_lo(p.x)); v[1] = __float_as_uint(bound_lo(p.y)); v[2] = __float_as_uint(bound_lo(p.z));
+            u[0] = __float_as_uint(bound_hi(p.x)); u[1] = __float_as_uint(bound_hi(p.y)); u[2] = __float_as_uint(bound_hi(p.z));
             int lo = 0, hi = F;   // largest sg with s_seg[sg] <= i
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
@@ -168,7 +179,7 @@ __global__ __launch_bounds__(256) void k_frontier_bbox(int n, const Float4 *__re
         if (__all(valid && sg == sg0)) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                uint32_t mn = v[k], mx = v[k];
+                uint32_t mn = v[k], mx = u[k];
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) {
                     mn = min(mn, (uint32_t) __shfl_xor((int) mn, o, 64));
@@ -178,7 +189,7 @@ __global__ __launch_bounds__(256) void k_frontier_bbox(int n, const Float4 *__re
             }
         } else if (valid) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { atomicMin(&s_box[sg][k], v[k]); atomicMax(&s_box[sg][3 + k], v[k]); }
+            for (int k = 0; k < 3; ++k) { atomicMin(&s_box[sg][k], v[k]); atomicMax(&s_box[sg][3 + k], u[k]); }
         }
     }
     __syncthreads();
@@ -204,8 +215,9 @@ __global__ __launch_bounds__(256) void k_frontier_bbox(int n, const Float4 *__re
 // a leaf, nothing otherwise (its children decide).  No stack, no queue; output slots come
 // from one atomic per workgroup and domain.
 // ---------------------------------------------------------------------------
+template <typename R4>
 __global__ __launch_bounds__(256) void k_let_mask(const Counts *counts,
-                                                  const Float4 *__restrict__ nodeA,
+                                                  const R4 *__restrict__ nodeA,
                                                   const NodeB *__restrict__ nodeB,
                                                   const float *__restrict__ frontiers, int ndom,
                                                   int T, int skip, float theta,
@@ -234,7 +246,7 @@ __global__ __launch_bounds__(256) void k_let_mask(const Counts *counts,
         const NodeB B = nodeB[o];
         uint32_t bits = 0;
         if (!(B.meta & NODE_LEAF)) {
-            const Float4 A = nodeA[o];
+            const Float4 A = narrow4(nodeA[o]);   // (the criterion in float for double handles too)
             const float sz2 = B.size * B.size;
             for (int d = 0; d < ndom; ++d) {
                 if (d == skip) continue;
@@ -389,9 +401,10 @@ __global__ __launch_bounds__(256) void k_let_tree_scan(const Counts *counts, int
     if (threadIdx.x == 0) { out_count[2 * dom] = carry[0]; out_count[2 * dom + 1] = carry[2]; }
 }
 
+template <typename R4>
 __global__ __launch_bounds__(256) void k_let_tree_emit(
-    const Counts *counts, const Float4 *__restrict__ nodeA, const NodeB *__restrict__ nodeB,
-    const Float4 *__restrict__ posm, const uint32_t *__restrict__ mask,
+    const Counts *counts, const R4 *__restrict__ nodeA, const NodeB *__restrict__ nodeB,
+    const R4 *__restrict__ posm, const uint32_t *__restrict__ mask,
     const uint32_t *__restrict__ reach, int skip, int nblk, const uint32_t *__restrict__ bsum,
     const uint32_t *__restrict__ out_count, unsigned char *__restrict__ out, size_t cap_bytes)
 {
@@ -400,9 +413,10 @@ __global__ __launch_bounds__(256) void k_let_tree_emit(
     if (dom == skip) return;
     const int n_oct = counts->n_oct;
     if ((int) blockIdx.x * 256 >= n_oct) return;
+    constexpr size_t NODE_BYTES = sizeof(R4) + sizeof(NodeB), PART_BYTES = sizeof(R4);
     const uint32_t tot_nodes = out_count[2 * dom], tot_parts = out_count[2 * dom + 1];
     // over capacity: nothing is written, the caller sees the counts and comes back with more room
-    if ((size_t) tot_nodes * 32 + (size_t) tot_parts * 16 > cap_bytes) return;
+    if ((size_t) tot_nodes * NODE_BYTES + (size_t) tot_parts * PART_BYTES > cap_bytes) return;
     const int o = blockIdx.x * 256 + threadIdx.x;
     NodeB me;
     int kind;
@@ -414,10 +428,10 @@ __global__ __launch_bounds__(256) void k_let_tree_emit(
     const uint32_t *b3 = bsum + ((size_t) dom * nblk + blockIdx.x) * 3;
     const uint32_t R = b3[0] + (ex0 & 0xfffu), S = b3[1] + (ex0 >> 12), P = b3[2] + ex1;
     unsigned char *seg = out + (size_t) dom * cap_bytes;
-    Float4 *nA = reinterpret_cast<Float4 *>(seg + (size_t) R * 32);
-    NodeB *nB = reinterpret_cast<NodeB *>(seg + (size_t) R * 32 + 16);
-    Float4 *parts = reinterpret_cast<Float4 *>(seg + (size_t) tot_nodes * 32);
-    const Float4 A = nodeA[o];
+    R4 *nA = reinterpret_cast<R4 *>(seg + (size_t) R * NODE_BYTES);
+    NodeB *nB = reinterpret_cast<NodeB *>(seg + (size_t) R * NODE_BYTES + sizeof(R4));
+    R4 *parts = reinterpret_cast<R4 *>(seg + (size_t) tot_nodes * NODE_BYTES);
+    const R4 A = nodeA[o];
     *nA = A;
     if (kind == 3) {
         // kept: its children follow.  Marked as "leaf child" (taken without a test) are the
@@ -440,12 +454,14 @@ __global__ __launch_bounds__(256) void k_let_tree_emit(
 // node indices [node_base[r], +nn[r]) and the particle indices [part_base[r], +np[r]); `first`
 // of every node is rebased accordingly.  desc = 5 ints per copy: off/16, nn, np, node_base, part_base;
 // item_prefix[r] = nodes + particles of the copies before r.
+template <typename R4>
 __global__ __launch_bounds__(256) void k_let_graft(int ncopies, const int32_t *__restrict__ desc,
                                                    const int32_t *__restrict__ item_prefix,
                                                    const unsigned char *__restrict__ recv,
-                                                   Float4 *__restrict__ nodeA, NodeB *__restrict__ nodeB,
-                                                   Float4 *__restrict__ posm, float *__restrict__ posm2)
+                                                   R4 *__restrict__ nodeA, NodeB *__restrict__ nodeB,
+                                                   R4 *__restrict__ posm, float *__restrict__ posm2)
 {
+    constexpr size_t NODE_BYTES = sizeof(R4) + sizeof(NodeB), PART_BYTES = sizeof(R4);
     const int total = item_prefix[ncopies];
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         int lo = 0, hi = ncopies;   // largest r with item_prefix[r] <= i
@@ -457,18 +473,20 @@ __global__ __launch_bounds__(256) void k_let_graft(int ncopies, const int32_t *_
         const int j = i - item_prefix[lo];
         const unsigned char *src = recv + (size_t) d[0] * 16;
         if (j < d[1]) {
-            const Float4 A = *reinterpret_cast<const Float4 *>(src + (size_t) j * 32);
-            NodeB B = *reinterpret_cast<const NodeB *>(src + (size_t) j * 32 + 16);
+            const R4 A = *reinterpret_cast<const R4 *>(src + (size_t) j * NODE_BYTES);
+            NodeB B = *reinterpret_cast<const NodeB *>(src + (size_t) j * NODE_BYTES + sizeof(R4));
             B.first += (B.meta & NODE_LEAF) ? d[4] : d[3];
             nodeA[d[3] + j] = A;
             nodeB[d[3] + j] = B;
         } else {
             const int k = j - d[1];
-            const Float4 p = *reinterpret_cast<const Float4 *>(src + (size_t) d[1] * 32 + (size_t) k * 16);
+            const R4 p = *reinterpret_cast<const R4 *>(src + (size_t) d[1] * NODE_BYTES + (size_t) k * PART_BYTES);
             const size_t q = (size_t) d[4] + k;
             posm[q] = p;
-            float *r = posm2 + (q >> 1) * 8 + (q & 1);
-            r[0] = p.x; r[2] = p.y; r[4] = p.z; r[6] = p.w;
+            if (posm2) {   // float handles: the pair-interleaved copy the traversal streams
+                float *r = posm2 + (q >> 1) * 8 + (q & 1);
+                r[0] = (float) p.x; r[2] = (float) p.y; r[4] = (float) p.z; r[6] = (float) p.w;
+            }
         }
     }
 }
@@ -509,34 +527,41 @@ __global__ __launch_bounds__(256) void k_key_lower_bound(const KeyT *__restrict_
     out[j] = lo;
 }
 
-constexpr int MIG_WORDS = 11;
+constexpr int MIG_WORDS = 11;   // of the handle's precision: 44 bytes (float), 88 (double)
 
+__device__ __forceinline__ float id_as_word(uint32_t id, float) { return __uint_as_float(id); }
+__device__ __forceinline__ double id_as_word(uint32_t id, double) { return __longlong_as_double((long long) id); }
+__device__ __forceinline__ uint32_t word_as_id(float w) { return __float_as_uint(w); }
+__device__ __forceinline__ uint32_t word_as_id(double w) { return (uint32_t) __double_as_longlong(w); }
+
+template <typename R>
 __global__ __launch_bounds__(256) void k_pack_particles(
-    int n, const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z,
-    const float *__restrict__ vx, const float *__restrict__ vy, const float *__restrict__ vz,
-    const float *__restrict__ m, const float *__restrict__ ax, const float *__restrict__ ay,
-    const float *__restrict__ az, const uint32_t *__restrict__ id, float *__restrict__ out)
+    int n, const R *__restrict__ x, const R *__restrict__ y, const R *__restrict__ z,
+    const R *__restrict__ vx, const R *__restrict__ vy, const R *__restrict__ vz,
+    const R *__restrict__ m, const R *__restrict__ ax, const R *__restrict__ ay,
+    const R *__restrict__ az, const uint32_t *__restrict__ id, R *__restrict__ out)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    float *r = out + (size_t) i * MIG_WORDS;
+    R *r = out + (size_t) i * MIG_WORDS;
     r[0] = x[i]; r[1] = y[i]; r[2] = z[i]; r[3] = vx[i]; r[4] = vy[i]; r[5] = vz[i]; r[6] = m[i];
-    r[7] = ax[i]; r[8] = ay[i]; r[9] = az[i]; r[10] = __uint_as_float(id[i]);
+    r[7] = ax[i]; r[8] = ay[i]; r[9] = az[i]; r[10] = id_as_word(id[i], R(0));
 }
 
 // The accelerations ride in the half-step velocity arrays (dead between two steps) so that
 // the permute of the following sort carries them along.
+template <typename R>
 __global__ __launch_bounds__(256) void k_unpack_particles(
-    int n, const float *__restrict__ in, float *__restrict__ x, float *__restrict__ y,
-    float *__restrict__ z, float *__restrict__ vx, float *__restrict__ vy, float *__restrict__ vz,
-    float *__restrict__ m, float *__restrict__ hx, float *__restrict__ hy, float *__restrict__ hz,
+    int n, const R *__restrict__ in, R *__restrict__ x, R *__restrict__ y,
+    R *__restrict__ z, R *__restrict__ vx, R *__restrict__ vy, R *__restrict__ vz,
+    R *__restrict__ m, R *__restrict__ hx, R *__restrict__ hy, R *__restrict__ hz,
     uint32_t *__restrict__ id)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float *r = in + (size_t) i * MIG_WORDS;
+    const R *r = in + (size_t) i * MIG_WORDS;
     x[i] = r[0]; y[i] = r[1]; z[i] = r[2]; vx[i] = r[3]; vy[i] = r[4]; vz[i] = r[5]; m[i] = r[6];
-    hx[i] = r[7]; hy[i] = r[8]; hz[i] = r[9]; id[i] = __float_as_uint(r[10]);
+    hx[i] = r[7]; hy[i] = r[8]; hz[i] = r[9]; id[i] = word_as_id(r[10]);
 }
 
 hipError_t launch_key_lower_bound(Sim *s, const uint64_t *queries_dev, int nq, int32_t *out_dev)
@@ -552,23 +577,36 @@ hipError_t launch_key_lower_bound(Sim *s, const uint64_t *queries_dev, int nq, i
     return hipGetLastError();
 }
 
-hipError_t launch_pack_particles(Sim *s, float *out)
+hipError_t launch_pack_particles(Sim *s, void *out)
 {
     const int c = s->cur;
     if (s->n < 1) return hipSuccess;
-    hipLaunchKernelGGL(k_pack_particles, dim3((s->n + 255) / 256), dim3(256), 0, s->stream, s->n, s->x[c],
-                       s->y[c], s->z[c], s->vx[c], s->vy[c], s->vz[c], s->m[c], s->ax, s->ay, s->az,
-                       s->id[c], out);
+    const dim3 grid((s->n + 255) / 256);
+    if (s->fp64) {
+        State64 &d = s->d;
+        hipLaunchKernelGGL(k_pack_particles<double>, grid, dim3(256), 0, s->stream, s->n, d.x[c], d.y[c], d.z[c],
+                           d.vx[c], d.vy[c], d.vz[c], d.m[c], d.ax, d.ay, d.az, s->id[c], (double *) out);
+    } else {
+        hipLaunchKernelGGL(k_pack_particles<float>, grid, dim3(256), 0, s->stream, s->n, s->x[c], s->y[c], s->z[c],
+                           s->vx[c], s->vy[c], s->vz[c], s->m[c], s->ax, s->ay, s->az, s->id[c], (float *) out);
+    }
     return hipGetLastError();
 }
 
-hipError_t launch_unpack_particles(Sim *s, const float *in, int n)
+hipError_t launch_unpack_particles(Sim *s, const void *in, int n)
 {
     const int c = s->cur;
     if (n < 1) return hipSuccess;
-    hipLaunchKernelGGL(k_unpack_particles, dim3((n + 255) / 256), dim3(256), 0, s->stream, n, in, s->x[c],
-                       s->y[c], s->z[c], s->vx[c], s->vy[c], s->vz[c], s->m[c], s->vhx[c], s->vhy[c],
-                       s->vhz[c], s->id[c]);
+    const dim3 grid((n + 255) / 256);
+    if (s->fp64) {
+        State64 &d = s->d;
+        hipLaunchKernelGGL(k_unpack_particles<double>, grid, dim3(256), 0, s->stream, n, (const double *) in, d.x[c],
+                           d.y[c], d.z[c], d.vx[c], d.vy[c], d.vz[c], d.m[c], d.vhx[c], d.vhy[c], d.vhz[c], s->id[c]);
+    } else {
+        hipLaunchKernelGGL(k_unpack_particles<float>, grid, dim3(256), 0, s->stream, n, (const float *) in, s->x[c],
+                           s->y[c], s->z[c], s->vx[c], s->vy[c], s->vz[c], s->m[c], s->vhx[c], s->vhy[c],
+                           s->vhz[c], s->id[c]);
+    }
     return hipGetLastError();
 }
 
@@ -582,10 +620,18 @@ hipError_t launch_bbox(Sim *s, uint32_t *box_dev)
 // records_dev: T * LET_REC floats.  seg: LET_MAX_T + 2 ints of scratch.
 hipError_t launch_frontier(Sim *s, float *records_dev, int T)
 {
-    hipLaunchKernelGGL(k_frontier_select, dim3(1), dim3(256), 0, s->stream, s->counts, s->n, T,
-                       s->nodeB, s->nodeA, s->o_pb, s->o_pe, records_dev, s->let_seg);
-    hipLaunchKernelGGL(k_frontier_bbox, dim3(std::min((s->n + 255) / 256, 1024)), dim3(256), 0, s->stream, s->n,
-                       s->posm, s->let_seg, records_dev);
+    const int grid = std::min((s->n + 255) / 256, 1024);
+    if (s->fp64) {
+        hipLaunchKernelGGL(k_frontier_select<Double4>, dim3(1), dim3(256), 0, s->stream, s->counts, s->n, T,
+                           s->nodeB, s->d.nodeA, s->o_pb, s->o_pe, records_dev, s->let_seg);
+        hipLaunchKernelGGL(k_frontier_bbox<Double4>, dim3(grid), dim3(256), 0, s->stream, s->n, s->d.posm,
+                           s->let_seg, records_dev);
+    } else {
+        hipLaunchKernelGGL(k_frontier_select<Float4>, dim3(1), dim3(256), 0, s->stream, s->counts, s->n, T,
+                           s->nodeB, s->nodeA, s->o_pb, s->o_pe, records_dev, s->let_seg);
+        hipLaunchKernelGGL(k_frontier_bbox<Float4>, dim3(grid), dim3(256), 0, s->stream, s->n, s->posm,
+                           s->let_seg, records_dev);
+    }
     return hipGetLastError();
 }
 
@@ -599,7 +645,7 @@ hipError_t launch_let_export(Sim *s, const float *frontiers_dev, int ndom, int T
     // grids from the host-known upper bound of the node count (2n); surplus threads exit
     const int gx = (2 * s->n + 255) / 256;
     const size_t lds = ((size_t) ndom * T * 6 + (size_t) ndom * 6) * sizeof(float);
-    hipLaunchKernelGGL(k_let_mask, dim3(std::min(gx, 2048)), dim3(256), lds, s->stream, s->counts,
+    hipLaunchKernelGGL(k_let_mask<Float4>, dim3(std::min(gx, 2048)), dim3(256), lds, s->stream, s->counts,
                        s->nodeA, s->nodeB, frontiers_dev, ndom, T, skip, s->p.theta, s->let_mask);
     hipLaunchKernelGGL(k_let_emit, dim3(gx, ndom), dim3(256), 0, s->stream, s->counts, s->nodeA,
                        s->nodeB, s->o_parent, s->posm, s->let_mask, skip, out, cap, out_count);
@@ -613,17 +659,26 @@ hipError_t launch_let_export_tree(Sim *s, const float *frontiers_dev, int ndom, 
 {
     const int nblk = (2 * s->n + 255) / 256;
     const size_t lds = ((size_t) ndom * T * 6 + (size_t) ndom * 6) * sizeof(float);
-    hipLaunchKernelGGL(k_let_mask, dim3(std::min(nblk, 2048)), dim3(256), lds, s->stream, s->counts,
-                       s->nodeA, s->nodeB, frontiers_dev, ndom, T, skip, s->p.theta, s->let_mask);
+    if (s->fp64)
+        hipLaunchKernelGGL(k_let_mask<Double4>, dim3(std::min(nblk, 2048)), dim3(256), lds, s->stream, s->counts,
+                           s->d.nodeA, s->nodeB, frontiers_dev, ndom, T, skip, s->p.theta, s->let_mask);
+    else
+        hipLaunchKernelGGL(k_let_mask<Float4>, dim3(std::min(nblk, 2048)), dim3(256), lds, s->stream, s->counts,
+                           s->nodeA, s->nodeB, frontiers_dev, ndom, T, skip, s->p.theta, s->let_mask);
     hipLaunchKernelGGL(k_let_reach, dim3(std::min(nblk, 2048)), dim3(256), 0, s->stream, s->counts,
                        s->o_parent, s->let_mask, s->let_reach);
     hipLaunchKernelGGL(k_let_tree_count, dim3(nblk, ndom), dim3(256), 0, s->stream, s->counts, s->nodeB,
                        s->let_mask, s->let_reach, skip, nblk, s->let_bsum);
     hipLaunchKernelGGL(k_let_tree_scan, dim3(ndom), dim3(256), 0, s->stream, s->counts, skip, nblk,
                        s->let_bsum, out_count);
-    hipLaunchKernelGGL(k_let_tree_emit, dim3(nblk, ndom), dim3(256), 0, s->stream, s->counts, s->nodeA,
-                       s->nodeB, s->posm, s->let_mask, s->let_reach, skip, nblk, s->let_bsum, out_count, out,
-                       cap_bytes);
+    if (s->fp64)
+        hipLaunchKernelGGL(k_let_tree_emit<Double4>, dim3(nblk, ndom), dim3(256), 0, s->stream, s->counts, s->d.nodeA,
+                           s->nodeB, s->d.posm, s->let_mask, s->let_reach, skip, nblk, s->let_bsum, out_count, out,
+                           cap_bytes);
+    else
+        hipLaunchKernelGGL(k_let_tree_emit<Float4>, dim3(nblk, ndom), dim3(256), 0, s->stream, s->counts, s->nodeA,
+                           s->nodeB, s->posm, s->let_mask, s->let_reach, skip, nblk, s->let_bsum, out_count, out,
+                           cap_bytes);
     return hipGetLastError();
 }
 
@@ -631,8 +686,13 @@ hipError_t launch_let_graft(Sim *s, int ncopies, const int32_t *desc_dev, const 
                             int total_items, const unsigned char *recv)
 {
     if (total_items < 1) return hipSuccess;
-    hipLaunchKernelGGL(k_let_graft, dim3(std::min((total_items + 255) / 256, 4096)), dim3(256), 0, s->stream,
-                       ncopies, desc_dev, prefix_dev, recv, s->nodeA, s->nodeB, s->posm, s->posm2);
+    const int grid = std::min((total_items + 255) / 256, 4096);
+    if (s->fp64)
+        hipLaunchKernelGGL(k_let_graft<Double4>, dim3(grid), dim3(256), 0, s->stream, ncopies, desc_dev, prefix_dev,
+                           recv, s->d.nodeA, s->nodeB, s->d.posm, (float *) nullptr);
+    else
+        hipLaunchKernelGGL(k_let_graft<Float4>, dim3(grid), dim3(256), 0, s->stream, ncopies, desc_dev, prefix_dev,
+                           recv, s->nodeA, s->nodeB, s->posm, s->posm2);
     return hipGetLastError();
 }
 

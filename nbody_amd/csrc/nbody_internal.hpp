@@ -265,11 +265,14 @@ hipError_t launch_traverse_forest(Sim *s, int what, bool kick);
 // pending_vel itself).
 int traverse_forest(Sim *s, int what, int group_begin, int group_end, bool kick);
 hipError_t launch_key_lower_bound(Sim *s, const uint64_t *queries_dev, int nq, int32_t *out_dev);
-hipError_t launch_pack_particles(Sim *s, float *out);              // 11 words per particle
-hipError_t launch_unpack_particles(Sim *s, const float *in, int n);
+hipError_t launch_pack_particles(Sim *s, void *out);               // 11 words of the handle's precision per particle
+hipError_t launch_unpack_particles(Sim *s, const void *in, int n);
 // Sort + build over the n particles k_unpack_particles has just put into the current buffers
 // (accelerations in the half-step velocity arrays); everything on the handle's stream.
 int install_particles_dev(Sim *s, int n);
+// Samples particles [first, first + count) of a set of n_total in the handle's precision and
+// installs them (ids = index in the whole set); the handle is sorted and built afterwards.
+int spawn_range(Sim *s, int kind, long long first, int count, long long n_total, float p0, float p1);
 // Host sampler of the initial conditions for particle indices [first, first + count) of a set of
 // n_total particles.
 int sample_ic_range(int kind, long long first, int count, long long n_total, uint64_t seed, float domain,
@@ -299,6 +302,7 @@ hipError_t launch64_morton_only(Sim *s);
 hipError_t launch64_permute(Sim *s, bool all_fields);
 hipError_t launch64_com(Sim *s);
 hipError_t launch64_traverse(Sim *s, bool potential);       // -> d.ax/ay/az, or d.pot
+hipError_t launch64_traverse_forest(Sim *s, int what);      // own tree and/or imported copies
 hipError_t launch64_vel_kick(Sim *s);
 hipError_t launch64_export_view(Sim *s);
 hipError_t launch64_direct(const Double4 *targets, int nt, const Double4 *sources, int ns,

@@ -18,8 +18,15 @@ pytestmark = pytest.mark.gpu
 LEAF = 0x80000000
 
 
-def parse_copy(raw, nn, npart):
-    """Node and particle records of one exported copy: raw uint8 array of 32 nn + 16 npart bytes."""
+def parse_copy(raw, nn, npart, f64=False):
+    """Node and particle records of one exported copy: raw uint8 array of 32 nn + 16 npart bytes
+    (float handles), 48 nn + 32 npart (double handles: four doubles, then size/first/count/meta)."""
+    if f64:
+        rec = raw[:48 * nn].reshape(nn, 48)
+        ints = rec[:, 32:].copy().view(np.int32).reshape(nn, 4)
+        return {"com": rec[:, :32].copy().view(np.float64).reshape(nn, 4), "size": ints[:, 0].copy().view(np.float32),
+                "first": ints[:, 1].copy(), "count": ints[:, 2].copy(), "meta": ints[:, 3].copy().view(np.uint32),
+                "parts": raw[48 * nn:48 * nn + 32 * npart].copy().view(np.float64).reshape(npart, 4)}
     nodes = raw[:32 * nn].view(np.float32).reshape(nn, 8)
     ints = raw[:32 * nn].view(np.int32).reshape(nn, 8)
     parts = raw[32 * nn:32 * nn + 16 * npart].view(np.float32).reshape(npart, 4)
@@ -30,13 +37,16 @@ def parse_copy(raw, nn, npart):
 class ForestDomains:
     """`world` domains on this GPU, stepped with the calls nbody_dd_step makes."""
 
-    def __init__(self, ic, world, bits, theta, eps=0.01, dt=1e-3, records=T, cap_bytes=1024, group=64):
+    def __init__(self, ic, world, bits, theta, eps=0.01, dt=1e-3, records=T, cap_bytes=1024, group=64, f64=False):
         self.parts = key_ranges(ic, world, bits)
+        self.nb, self.pb = (48, 32) if f64 else (32, 16)       # bytes per node and particle record
         self.records, self.cap = records, cap_bytes           # a small capacity forces a regrow
         self.sims = []
         for idx in self.parts:
             p = _params(len(idx), bits, theta, eps, dt)
             p.traversal_group_size = group
+            if f64:
+                p.flags |= nb.FLAG_FP64
             s = nb.Simulation(p)
             s.set_state(ic["x"][idx], ic["y"][idx], ic["z"][idx], ic["m"][idx], ic["vx"][idx],
                         ic["vy"][idx], ic["vz"][idx])
@@ -61,13 +71,13 @@ class ForestDomains:
                 s.let_export_tree_dev(self.frontiers.data_ptr(), W, R, r, out.data_ptr(), self.cap, cnt.data_ptr())
                 s.sync()
                 c = cnt.cpu().numpy().reshape(W, 2)
-                need = int((32 * c[:, 0] + 16 * c[:, 1]).max())
+                need = int((self.nb * c[:, 0] + self.pb * c[:, 1]).max())
                 if need <= self.cap:
                     break
                 assert not out.any()                          # over capacity: nothing was written
                 self.cap = (int(need * 1.25) + 64) // 16 * 16
             assert c[r, 0] == 0 and c[r, 1] == 0
-            self.copies.append({q: (out[q, :32 * c[q, 0] + 16 * c[q, 1]].clone(), int(c[q, 0]), int(c[q, 1]))
+            self.copies.append({q: (out[q, :self.nb * c[q, 0] + self.pb * c[q, 1]].clone(), int(c[q, 0]), int(c[q, 1]))
                                 for q in range(W) if q != r})
             if flat:   # the flat export of the same tree against the same frontiers
                 fcap = max(int(c[:, 1].max()), 1)
@@ -140,12 +150,13 @@ def _f32_fma(a, b, c):
     return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
 
 
-def walk_copy(t, bx, by, bz, theta, domain):
+def walk_copy(t, bx, by, bz, theta, domain, f64=False):
     """Sources (indices into t['parts'] and node ids accepted as (com, mass)) a group of bodies
     takes from a copy: a child its parent marks is taken whole without a test; any other node,
     leaf or not, is accepted as one source iff size^2 / min_b |x_b - com|^2 < theta^2 (float32,
     the kernel's operation order), else a leaf is taken whole and an inner node opened."""
-    th2 = np.float32(theta) * np.float32(theta)
+    real = np.float64 if f64 else np.float32
+    th2 = real(np.float32(theta)) * real(np.float32(theta))
     leaf = (t["meta"] & LEAF) != 0
     parts, coms = [], []
     stack = [(0, False)]
@@ -155,10 +166,13 @@ def walk_copy(t, bx, by, bz, theta, domain):
             parts.extend(range(t["first"][o], t["first"][o] + t["count"][o]))
             continue
         dx, dy, dz = bx - t["com"][o, 0], by - t["com"][o, 1], bz - t["com"][o, 2]
-        d2 = _f32_fma(dz, dz, _f32_fma(dy, dy, dx * dx))
-        dmin = min(np.float32(3.0) * np.float32(domain) * np.float32(domain), d2.min())
+        # (double: the kernel's fused multiply-adds round differently only in the last bit, which
+        # decides a test once in about 1e13)
+        d2 = dz * dz + (dy * dy + dx * dx) if f64 else _f32_fma(dz, dz, _f32_fma(dy, dy, dx * dx))
+        dmin = min(real(3.0) * real(domain) * real(domain), d2.min())
+        size = real(t["size"][o])
         with np.errstate(divide="ignore"):
-            if (t["size"][o] * t["size"][o]) / dmin < th2:
+            if (size * size) / dmin < th2:
                 coms.append(o)
             elif leaf[o]:
                 parts.extend(range(t["first"][o], t["first"][o] + t["count"][o]))
@@ -274,3 +288,50 @@ def test_forest_without_copies_is_the_plain_traversal():
             assert np.array_equal(sa[k], sb[k])
         with pytest.raises(RuntimeError):
             b.import_trees_dev(0, [8], [1], [1])          # offsets are multiples of 16
+
+
+def test_forest_of_double_handles_equals_numpy_restatement():
+    """Double handles: copies carry doubles (48-byte nodes, 32-byte particles), the criterion and
+    the sums run in double.  Lists exact, forces to 1e-11 against the oracle's double traversal
+    of the own tree plus a numpy walk of the shipped copies."""
+    n, theta, eps, bits, group, world = 3000, 0.6, 0.02, 21, 64, 3
+    ic = nb.sample_ic(nb.IC_SPHERE, n, 21, dtype=np.float64)
+    d = ForestDomains(ic, world, bits, theta, eps, group=group, f64=True)
+    d.step()
+    e2 = float(np.float32(eps)) ** 2                      # the handle keeps its parameters as floats
+    for r, s in enumerate(d.sims):
+        st = s.get_state()
+        assert st["x"].dtype == np.float64
+        ll = s.get_list_len()
+        b = O.full_build_dp(st["x"], st["y"], st["z"], st["m"], DOMAIN, bits, 32)
+        ax, ay, az, own_ll = O.traverse_dp(b["tree"], b["com"], b["xs"], b["ys"], b["zs"], b["ms"], group, theta,
+                                           eps, 1.0, DOMAIN)
+        want = [np.array(ax, np.float64), np.array(ay, np.float64), np.array(az, np.float64)]
+        want_ll = np.array(own_ll, np.int64)
+        copies = [parse_copy(raw.cpu().numpy(), nn, npart, True)
+                  for q in range(world) if q != r for raw, nn, npart in [d.copies[q][r]]]
+        nloc = len(st["x"])
+        for g in range((nloc + group - 1) // group):
+            sl = slice(g * group, min((g + 1) * group, nloc))
+            bx, by, bz = st["x"][sl], st["y"][sl], st["z"][sl]
+            for t in copies:
+                parts, coms = walk_copy(t, bx, by, bz, theta, DOMAIN, True)
+                src = np.concatenate([t["parts"][parts].reshape(-1, 4), t["com"][coms].reshape(-1, 4)])
+                want_ll[g] += len(src)
+                dx, dy, dz = (src[None, :, k] - c[:, None] for k, c in enumerate((bx, by, bz)))
+                inv = src[None, :, 3] / (dx * dx + dy * dy + dz * dz + e2) ** 1.5
+                want[0][sl] += (dx * inv).sum(1); want[1][sl] += (dy * inv).sum(1); want[2][sl] += (dz * inv).sum(1)
+        assert np.array_equal(ll, want_ll)
+        scale = np.sqrt(want[0] ** 2 + want[1] ** 2 + want[2] ** 2)
+        for got, w in zip((st["ax"], st["ay"], st["az"]), want):
+            assert np.max(np.abs(got - w) / scale) < 1e-11
+    # against the all-pairs sum in double: the tree's own error, nothing else
+    x, y, z, m, ax, ay, az = (np.empty(n, np.float64) for _ in range(7))
+    for idx, s in zip(d.parts, d.sims):
+        st = s.get_state()
+        g = idx[st["id"]]
+        x[g], y[g], z[g], m[g] = st["x"], st["y"], st["z"], st["m"]
+        ax[g], ay[g], az[g] = st["ax"], st["ay"], st["az"]
+    d.close()
+    mean, mx = O.acc_error(ax, ay, az, *O.direct_f64(x, y, z, m, eps, 1.0))
+    assert mean < 1e-2 and mx < 0.3

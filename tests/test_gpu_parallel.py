@@ -129,12 +129,22 @@ def test_domain_decomposition_single_rank_is_a_plain_step(single_rank_group):
         assert np.array_equal(sa[k], sb[k]), k
 
 
-def test_domain_decomposition_refuses_handles_it_cannot_step(single_rank_group):
-    """The exchange is float-only: a double handle is refused when the stepper is created, not
-    later.  A handle with a fitted key domain is accepted (the ranks then draw one cube together)."""
-    with nb.Simulation(nb.Params(num_points=1000, device_id=0, flags=nb.FLAG_FP64)) as sim:
-        with pytest.raises(RuntimeError, match="nbody_dd_create failed"):
-            parallel.DomainDecomposition(sim, "cuda:0")
+def test_domain_decomposition_accepts_double_and_fitted_handles(single_rank_group):
+    """A double handle steps like a plain double update(); a handle with a fitted key domain is
+    accepted too (the ranks then draw one cube together)."""
+    kw = dict(num_points=3000, morton_bits=21, theta=0.5, dt=1e-3, softening_factor=0.01, device_id=0, seed=9,
+              flags=nb.FLAG_FP64)
+    with nb.Simulation(nb.Params(**kw)) as a, nb.Simulation(nb.Params(**kw)) as b:
+        a.spawn_sphere()
+        with parallel.DomainDecomposition(b, "cuda:0") as dd:
+            dd.spawn(nb.IC_SPHERE, 3000)
+            for _ in range(2):
+                a.update()
+                dd.step()
+        sa, sb = a.get_state(), b.get_state()
+    assert sb["x"].dtype == np.float64
+    for k in ("x", "vx", "ax", "az"):
+        assert np.array_equal(sa[k][np.argsort(sa["id"])], sb[k][np.argsort(sb["id"])]), k
     with nb.Simulation(nb.Params(num_points=1000, morton_bits=10, device_id=0, flags=nb.FLAG_FIT_KEYS)) as sim:
         with parallel.DomainDecomposition(sim, "cuda:0") as dd:
             dd.spawn(nb.IC_SPHERE, 1000)
@@ -173,7 +183,8 @@ import nbody_amd as nb
 from nbody_amd import parallel
 rank, world, n = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(sys.argv[2])
 bits = int(sys.argv[4])
-fit = nb.FLAG_FIT_KEYS if len(sys.argv) > 5 and sys.argv[5] == "fit" else 0
+mode = sys.argv[5] if len(sys.argv) > 5 else ""
+fit = {"fit": nb.FLAG_FIT_KEYS, "fp64": nb.FLAG_FP64}.get(mode, 0)
 dist.init_process_group("gloo", rank=rank, world_size=world)
 cap = int(n / world * 1.5) + 64                      # head-room for the re-balance
 sim = nb.Simulation(nb.Params(num_points=cap, morton_bits=bits, theta=0.6, dt=1e-3,
@@ -193,7 +204,7 @@ s = sim.get_state()
 t = sim.get_timings()
 np.savez(sys.argv[3] + f"/rank{rank}.npz", gid=s["id"], gid1=s1["id"], keys0=keys0,
          split=np.array(st0["splitters"], np.uint64), sent=st1["records_sent"], recv=st1["records_received"],
-         n0=st0["n_local"], steps=t["steps"], inter=t["interactions"], cube=np.asarray(sim.key_domain(), np.float32),
+         n0=st0["n_local"], steps=t["steps"], inter=t["interactions"], cube=np.asarray(sim.key_domain() if mode != "fp64" else [0, 0, 0, 5], np.float32),
          **{k: s[k] for k in ("x", "y", "z", "m", "ax", "ay", "az")},
          **{k + "1": s1[k] for k in ("x", "y", "z", "m", "ax", "ay", "az")})
 dist.barrier()
@@ -203,13 +214,18 @@ dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("world,n,bits,fit", [(2, 12000, 21, False), (3, 9000, 21, False), (4, 8000, 10, False),
-                                              (3, 9000, 10, True), (2, 8000, 10, True)])
-def test_native_domain_decomposition_processes_share_the_gpu(tmp_path, world, n, bits, fit):
+@pytest.mark.parametrize("world,n,bits,mode", [(2, 12000, 21, ""), (3, 9000, 21, ""), (4, 8000, 10, ""),
+                                               (3, 9000, 10, "fit"), (2, 8000, 10, "fit"),
+                                               (2, 9000, 21, "fp64"), (3, 8000, 21, "fp64")])
+def test_native_domain_decomposition_processes_share_the_gpu(tmp_path, world, n, bits, mode):
     """nbody_dd_spawn / step / rebalance with `world` ranks (processes that share this GPU; the
     collectives are staged through host memory and gloo): ownership is by Morton-key range,
     every particle is owned once, forces checked against a float64 direct sum over all
-    particles and against the single-handle tree code."""
+    particles and against the single-handle tree code.  Modes: 30-bit keys fitted to one cube
+    across the ranks; double-precision handles (copies, migration records and sums in double)."""
+    fit, f64 = mode == "fit", mode == "fp64"
+    real = np.float64 if f64 else np.float32
+    flags = nb.FLAG_FIT_KEYS if fit else nb.FLAG_FP64 if f64 else 0
     script = tmp_path / "worker.py"
     script.write_text(_DD_WORKER)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -217,19 +233,19 @@ def test_native_domain_decomposition_processes_share_the_gpu(tmp_path, world, n,
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(n), str(tmp_path), str(bits)] + (["fit"] if fit else []),
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(n), str(tmp_path), str(bits), mode],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                                       text=True))
     for p in procs:
         out, _ = p.communicate(timeout=170)
         assert p.returncode == 0, out
-    ic = nb.sample_ic(nb.IC_SPHERE, n, 5)
+    ic = nb.sample_ic(nb.IC_SPHERE, n, 5, dtype=real)
     res = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     split = res[0]["split"]
     assert int(split[0]) == 0 and int(split[-1]) == 1 << (3 * bits)
     errs = {}
     for tag in ("1", ""):
-        full = {k: np.full(n, np.nan, np.float32) for k in ("x", "y", "z", "m", "ax", "ay", "az")}
+        full = {k: np.full(n, np.nan, real) for k in ("x", "y", "z", "m", "ax", "ay", "az")}
         for r, d in enumerate(res):
             gid = d["gid" + tag]
             for k in full:
@@ -255,11 +271,11 @@ def test_native_domain_decomposition_processes_share_the_gpu(tmp_path, world, n,
     # first step against the single-handle tree code on the same particles (same positions:
     # v = a = 0 at the first kick-drift; forces differ by the trees only)
     with nb.Simulation(nb.Params(num_points=n, morton_bits=bits, theta=0.6, dt=1e-3,
-                                 softening_factor=0.01, flags=nb.FLAG_FIT_KEYS if fit else 0)) as one:
+                                 softening_factor=0.01, flags=flags)) as one:
         one.set_state(ic["x"], ic["y"], ic["z"], ic["m"])
         one.update()
         s1 = one.get_state()
-    full1 = {k: np.empty(n, np.float32) for k in ("x", "y", "z", "m", "ax", "ay", "az")}
+    full1 = {k: np.empty(n, real) for k in ("x", "y", "z", "m", "ax", "ay", "az")}
     for d in res:
         for k in full1:
             full1[k][d["gid1"]] = d[k + "1"]
