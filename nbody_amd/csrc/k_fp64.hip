@@ -507,8 +507,8 @@ hipError_t launch64_com(Sim *s)
     const int grid = std::min((2 * s->n + 255) / 256, 2048);
     hipLaunchKernelGGL((k_com_t<double, Double4>), dim3(grid), dim3(256), 0, s->stream, s->counts, s->o_num_children,
                        s->o_first_child, s->o_pb, s->o_pe, s->o_parent, s->d.posm, s->d.wsum,
-                       s->d.nodeA, s->com_counter, s->depth_key, s->tickets + COM_ROOTS_TICKET,
-                       &s->counts->err);
+                       s->d.nodeA, s->com_counter, reinterpret_cast<const uint4 *>(s->depth_key),
+                       s->tickets + COM_ROOTS_TICKET, &s->counts->err);
     return hipGetLastError();
 }
 

@@ -56,16 +56,19 @@ __device__ __forceinline__ void reflect(float &p, float &v, float domain)
 }
 
 // v_half = v + 0.5*a*dt;  x += v_half*dt;  reflect;  code = morton(x).
-// 36 B read + 24 B + sizeof(KeyT) written per particle.
+// 36 B read + 24 B + sizeof(KeyT) written per particle.  The first zero16 threads also clear 16
+// bytes each of the scratch the sort and the tree build want zeroed (tickets, histograms,
+// look-back words: a few MB), which saves the step a memset launch.
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_integrate_morton(
     int n, float dt, float domain, float *__restrict__ x, float *__restrict__ y,
     float *__restrict__ z, const float *__restrict__ vx, const float *__restrict__ vy,
     const float *__restrict__ vz, const float *__restrict__ ax, const float *__restrict__ ay,
     const float *__restrict__ az, float *__restrict__ vhx, float *__restrict__ vhy,
-    float *__restrict__ vhz, KeyT *__restrict__ codes)
+    float *__restrict__ vhz, KeyT *__restrict__ codes, uint4 *__restrict__ zero, int zero16)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < zero16) zero[i] = uint4{0u, 0u, 0u, 0u};
     if (i >= n) return;
     float hx = fmaf(0.5f * ax[i], dt, vx[i]);
     float hy = fmaf(0.5f * ay[i], dt, vy[i]);
@@ -349,17 +352,23 @@ hipError_t launch_integrate_morton(Sim *s)
                            reinterpret_cast<uint32_t *>(s->keybox + 5));
         return launch_fit_and_encode(s);
     }
+    // the scratch of the sort and build that follow, cleared on the way when one thread per 16
+    // bytes is there for it (else the sort's own memset does it)
+    const size_t zb = scratch_zero_bytes(s);
+    const int zero16 = (zb % 16 == 0 && zb / 16 <= (size_t) nblk(s->n, 256) * 256) ? (int) (zb / 16) : 0;
     if (s->key_bytes == 4)
         hipLaunchKernelGGL(k_integrate_morton<uint32_t>, dim3(nblk(s->n, 256)), dim3(256), 0,
                            s->stream, s->n, s->p.dt, s->p.domain_size, s->x[c], s->y[c], s->z[c],
                            s->vx[c], s->vy[c], s->vz[c], s->ax, s->ay, s->az, s->vhx[c],
-                           s->vhy[c], s->vhz[c], (uint32_t *) s->keys[0]);
+                           s->vhy[c], s->vhz[c], (uint32_t *) s->keys[0], (uint4 *) s->zero_block, zero16);
     else
         hipLaunchKernelGGL(k_integrate_morton<uint64_t>, dim3(nblk(s->n, 256)), dim3(256), 0,
                            s->stream, s->n, s->p.dt, s->p.domain_size, s->x[c], s->y[c], s->z[c],
                            s->vx[c], s->vy[c], s->vz[c], s->ax, s->ay, s->az, s->vhx[c],
-                           s->vhy[c], s->vhz[c], (uint64_t *) s->keys[0]);
-    return hipGetLastError();
+                           s->vhy[c], s->vhz[c], (uint64_t *) s->keys[0], (uint4 *) s->zero_block, zero16);
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) s->scratch_prezeroed = zero16 ? zb : 0;
+    return e;
 }
 
 hipError_t launch_morton_only(Sim *s)

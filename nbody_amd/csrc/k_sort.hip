@@ -372,9 +372,13 @@ static hipError_t sort_impl(Sim *s)
     const int tiles = (n + SORT_TILE - 1) / SORT_TILE;   // <= s->sort_tiles (sized for cap)
     const int rows = sort_status_rows(tiles);            // tile rows + group rows of one pass
     const size_t zbytes = (8 * 256 + 16 + (size_t) (NPASS - P0) * rows * 256) * sizeof(uint32_t);
-    // one memset for this sort's scratch and for the tree build's, which lies just before it
-    hipError_t e = hipMemsetAsync(s->zero_block, 0, s->zero_bytes + zbytes, s->stream);
-    if (e != hipSuccess) return e;
+    // one memset for this sort's scratch and for the tree build's, which lies just before it --
+    // unless the kick-drift kernel of this step has zeroed them on its way (scratch_zero_bytes)
+    if (s->scratch_prezeroed != s->zero_bytes + zbytes) {
+        hipError_t e = hipMemsetAsync(s->zero_block, 0, s->zero_bytes + zbytes, s->stream);
+        if (e != hipSuccess) return e;
+    }
+    s->scratch_prezeroed = 0;
     s->build_scratch_zeroed = true;
     // layout of the zeroed block: ghist[8*256] | tickets[8] (+pad to 16) | status[P][rows][256]
     uint32_t *tickets = s->ghist + 8 * 256;
@@ -414,6 +418,18 @@ static hipError_t sort_impl(Sim *s)
                            (const uint32_t *) long_runs, (const uint32_t *) long_count);
     }
     return hipGetLastError();
+}
+
+template <typename KeyT, int NPASS, int P0>
+static size_t sort_zero_bytes(const Sim *s)
+{
+    const int tiles = (s->n + SORT_TILE - 1) / SORT_TILE;
+    return s->zero_bytes + (8 * 256 + 16 + (size_t) (NPASS - P0) * sort_status_rows(tiles) * 256) * sizeof(uint32_t);
+}
+
+size_t scratch_zero_bytes(const Sim *s)
+{
+    return s->key_bytes == 4 ? sort_zero_bytes<uint32_t, 4, 0>(s) : sort_zero_bytes<uint64_t, 8, NB_SORT_SKIP_DIGITS>(s);
 }
 
 hipError_t launch_sort(Sim *s)

@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) void k_emit(
     int32_t *__restrict__ o_lb, int32_t *__restrict__ o_le, int32_t *__restrict__ o_level,
     float *__restrict__ o_size, int32_t *__restrict__ o_pb, int32_t *__restrict__ o_pe,
     int32_t *__restrict__ o_parent, NodeB *__restrict__ nodeB, int com_local,
-    uint32_t *__restrict__ local_roots, uint32_t *n_local_roots)
+    uint4 *__restrict__ local_roots, uint32_t *n_local_roots)
 {
     const int n_bt = counts->n_bt;
     const int n_oct = n_bt - (int) dhist[255];
@@ -461,7 +461,9 @@ __global__ __launch_bounds__(256) void k_emit(
                 const int plb = rt_lb[p >> 1], ple = rt_le[p >> 1];
                 big_parent = first_pt[lfc[ple + 1]] - first_pt[lfc[plb]] > com_local;
             }
-            if (big_parent) local_roots[atomicAdd(n_local_roots, 1u)] = (uint32_t) o;
+            // (node, first particle, particles, parent): all the wave needs to get going
+            if (big_parent)
+                local_roots[atomicAdd(n_local_roots, 1u)] = uint4{(uint32_t) o, (uint32_t) pb, (uint32_t) (pe - pb + 1), (uint32_t) parent};
         }
     }
 }
@@ -504,7 +506,7 @@ static hipError_t build_impl(Sim *s)
                        s->rt_left, s->rt_right, s->lfc, s->first_pt, s->o_first_child,
                        s->o_num_children, s->o_lb, s->o_le, s->o_level, s->o_size, s->o_pb,
                        s->o_pe, s->o_parent, s->nodeB, s->fp64 ? com_local<double>() : com_local<float>(),
-                       s->depth_key, s->tickets + COM_ROOTS_TICKET);
+                       reinterpret_cast<uint4 *>(s->depth_key), s->tickets + COM_ROOTS_TICKET);
     return hipGetLastError();
 }
 
@@ -518,8 +520,8 @@ hipError_t launch_com(Sim *s)
     const int grid = std::min((2 * s->n + 255) / 256, 2048);
     hipLaunchKernelGGL((k_com_t<float, Float4>), dim3(grid), dim3(256), 0, s->stream, s->counts, s->o_num_children,
                        s->o_first_child, s->o_pb, s->o_pe, s->o_parent, s->posm, s->o_wsum,
-                       s->nodeA, s->com_counter, s->depth_key, s->tickets + COM_ROOTS_TICKET,
-                       &s->counts->err);
+                       s->nodeA, s->com_counter, reinterpret_cast<const uint4 *>(s->depth_key),
+                       s->tickets + COM_ROOTS_TICKET, &s->counts->err);
     return hipGetLastError();
 }
 

@@ -144,6 +144,7 @@ struct Sim {
     // scratch zeroed once per build (tickets, look-back words, counters, histograms)
     uint8_t *zero_block = nullptr;   // build part, then the sort's part (ghist points into it)
     bool build_scratch_zeroed = false;  // set by the sort's memset, consumed by the build
+    size_t scratch_prezeroed = 0;       // bytes of zero_block the kick-drift kernel has zeroed for the sort
     size_t zero_bytes = 0;
     uint32_t *tickets = nullptr;      // [8]
     uint32_t *scan_status = nullptr;  // [3][max_scan_tiles]
@@ -222,6 +223,7 @@ struct Sim {
 
 // ---- stage launchers (each enqueues on s->stream and returns a hipError_t) ----
 hipError_t launch_integrate_morton(Sim *s);                 // kick-drift + encode -> keys[0]
+size_t scratch_zero_bytes(const Sim *s);                    // what the sort of s->n keys wants zeroed in zero_block
 hipError_t launch_morton_only(Sim *s);                      // encode current positions
 hipError_t launch_keyfit_only(Sim *s);                      // cube decision from the box words
 hipError_t launch_bbox_merge(const uint32_t *all_dev, int ranks, uint32_t *box_dev, hipStream_t st);
