@@ -81,33 +81,34 @@ __device__ __forceinline__ uint32_t striped_offsets(const unsigned long long (&b
     return *s_tot;
 }
 
-template <typename KeyT>
+template <typename KeyT, int ITEMS>
 __global__ __launch_bounds__(SCAN_THREADS) void k_unique(const KeyT *__restrict__ sorted, int n,
                                                          KeyT *__restrict__ unique,
                                                          int32_t *__restrict__ first_pt,
                                                          Counts *counts, uint32_t *status,
                                                          uint32_t *group_status, uint32_t *ticket)
 {
-    __shared__ uint32_t s_cnt[SCAN_ITEMS * 4];
+    __shared__ uint32_t s_cnt[ITEMS * 4];
     __shared__ uint32_t s_bcast[3];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) s_bcast[0] = atomicAdd(ticket, 1u);
     __syncthreads();
     const int tile = (int) s_bcast[0];
-    const int ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    constexpr int TILE = SCAN_THREADS * ITEMS;
+    const int ntiles = (n + TILE - 1) / TILE;
     if (tile >= ntiles) return;
-    const int tile_base = tile * SCAN_TILE;
-    KeyT k[SCAN_ITEMS];
-    unsigned long long bal[SCAN_ITEMS];
+    const int tile_base = tile * TILE;
+    KeyT k[ITEMS];
+    unsigned long long bal[ITEMS];
 #pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; ++j) {
+    for (int j = 0; j < ITEMS; ++j) {
         const int gi = tile_base + j * SCAN_THREADS + tid;
         const int ci = min(gi, n - 1);
         k[j] = sorted[ci];
         const KeyT prev = sorted[max(ci - 1, 0)];       // (the neighbouring lane's line: a cache hit)
         bal[j] = __ballot(gi < n && (gi == 0 || k[j] != prev));
     }
-    const uint32_t tot = striped_offsets<SCAN_ITEMS>(bal, s_cnt, &s_bcast[2]);
+    const uint32_t tot = striped_offsets<ITEMS>(bal, s_cnt, &s_bcast[2]);
     if (tid < 64) {
         const uint32_t te = lb2_exclusive_wave(status, group_status, tile, tot, &counts->err);
         if (tid == 0) s_bcast[1] = te;
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_unique(const KeyT *__restrict_
     __syncthreads();
     const uint32_t tile_excl = s_bcast[1];
 #pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; ++j) {
+    for (int j = 0; j < ITEMS; ++j) {
         if ((bal[j] >> lane) & 1ull) {
             const uint32_t pos = tile_excl + s_cnt[j * 4 + w] + (uint32_t) mbcnt(bal[j]);
             unique[pos] = k[j];
@@ -479,11 +480,17 @@ static hipError_t build_impl(Sim *s)
     hipError_t e = s->build_scratch_zeroed ? hipSuccess : hipMemsetAsync(s->zero_block, 0, s->zero_bytes, st);
     if (e != hipSuccess) return e;
     s->build_scratch_zeroed = false;
-    const int scan_grid = (n + SCAN_TILE - 1) / SCAN_TILE;
     const KeyT *sorted = (const KeyT *) s->keys[s->sorted_buf];
-    hipLaunchKernelGGL(k_unique<KeyT>, dim3(scan_grid), dim3(SCAN_THREADS), 0, st, sorted, n,
-                       (KeyT *) s->unique, s->first_pt, s->counts, s->scan_status,
-                       s->scan_status + s->max_scan_tiles, s->tickets + 0);
+    // (a tile costs its place in the queue for the ticket, ~15 ns, whatever its size: large
+    // inputs take tiles of 8192 keys, small ones keep 4096 so that there are enough of them)
+    if (n >= (1 << 20))
+        hipLaunchKernelGGL((k_unique<KeyT, 2 * SCAN_ITEMS>), dim3((n + 2 * SCAN_TILE - 1) / (2 * SCAN_TILE)),
+                           dim3(SCAN_THREADS), 0, st, sorted, n, (KeyT *) s->unique, s->first_pt, s->counts,
+                           s->scan_status, s->scan_status + s->max_scan_tiles, s->tickets + 0);
+    else
+        hipLaunchKernelGGL((k_unique<KeyT, SCAN_ITEMS>), dim3((n + SCAN_TILE - 1) / SCAN_TILE), dim3(SCAN_THREADS),
+                           0, st, sorted, n, (KeyT *) s->unique, s->first_pt, s->counts, s->scan_status,
+                           s->scan_status + s->max_scan_tiles, s->tickets + 0);
     const int leaf_grid = (n + LEAF_TILE - 1) / LEAF_TILE;
     hipLaunchKernelGGL(k_leaves<KeyT>, dim3(leaf_grid), dim3(SCAN_THREADS), 0, st,
                        (const KeyT *) s->unique, s->p.max_num_codes_per_leaf, s->lfc,

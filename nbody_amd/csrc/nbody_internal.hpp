@@ -23,7 +23,10 @@ constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;
 // per group of NB_LB_GROUP tiles (dev_utils.hpp, lb2_exclusive_thread)
 constexpr int sort_status_rows(int tiles) { return tiles + (tiles + NB_LB_GROUP - 1) / NB_LB_GROUP; }
 constexpr int SCAN_THREADS = 256;
-constexpr int SCAN_ITEMS = 16;                      // elements per thread in compaction tiles
+#ifndef NB_SCAN_ITEMS
+#define NB_SCAN_ITEMS 16
+#endif
+constexpr int SCAN_ITEMS = NB_SCAN_ITEMS;           // elements per thread in compaction tiles
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 constexpr int LET_MAX_BOXES = 256;
 #ifndef NB_LET_MAX_T
