@@ -676,10 +676,12 @@ def main():
                                "note": f"{build_bytes} algorithmic B/particle over integrate+sort+permute+"
                                        f"build+COM with the {3 * args.morton_bits}-bit keys this run used "
                                        f"({BUILD_BYTES_PER_PARTICLE[10]} with 30-bit keys, "
-                                       f"{BUILD_BYTES_PER_PARTICLE[21]} with 63-bit keys); the same GB/s at "
-                                       "16.7 M particles (build time is linear in N): the digit passes run at "
-                                       "2.6 TB/s whatever the ranking and the load latency cost "
-                                       "(profiles/r3_sort_pass_experiments.txt), the waves of the tree and "
+                                       f"{BUILD_BYTES_PER_PARTICLE[21]} with 63-bit keys); 2.6 TB/s at 16.7 M "
+                                       "particles. Only kick-drift and permute stream at the chip's rate; a digit "
+                                       "pass is a chain per tile (ticket, load, rank, look-back, write) with two "
+                                       "workgroups per CU, no unit busy more than a third of the time, and the "
+                                       "same-address ticket atomics of every ticketed kernel complete 15 ns apart "
+                                       "(profiles/r3_sort_pass_experiments.txt); the waves of the tree and "
                                        "centre-of-mass kernels wait 80-85 % of their cycles on dependent loads "
                                        "(profiles/r3_build_kernels_pmc_2M_16M.txt)"},
         }

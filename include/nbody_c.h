@@ -464,7 +464,7 @@ int nbody_sample_ic_range(int kind, int64_t first, int32_t count, int64_t n_tota
                           float *z, float *vx, float *vy, float *vz, float *m);
 
 /* The collectives nbody_dd_* needs, supplied by the caller (RCCL in a C++ host, see
- * INTEGRATION.md; torch.distributed in the Python binding).  Both work on DEVICE memory, are
+ * examples/dd_rccl_main.cpp; torch.distributed in the Python binding).  Both work on DEVICE memory, are
  * ordered like kernels on the given hipStream_t (work queued on the stream before the call
  * precedes the collective, work queued after it follows), must not block the host longer than
  * enqueueing takes, and return 0 on success.
