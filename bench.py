@@ -682,7 +682,7 @@ def main():
                                        "workgroups per CU, no unit busy more than a third of the time, and the "
                                        "same-address ticket atomics of every ticketed kernel complete 15 ns apart "
                                        "(profiles/r3_sort_pass_experiments.txt); the waves of the tree and "
-                                       "centre-of-mass kernels wait 80-85 % of their cycles on dependent loads "
+                                       "centre-of-mass kernels wait 60-85 % of their cycles on dependent loads "
                                        "(profiles/r3_build_kernels_pmc_2M_16M.txt)"},
         }
         if world > 1:
