@@ -84,9 +84,14 @@ enum {
                                             32 usable entries, so that its overflow handling
                                             (push-backs, depth-first rounds) is exercised;
                                             results are unchanged                            */
-    NBODY_FLAG_DEBUG_WALK_ONLY = 1u << 8 /* profiling aid: traversal walks the tree and fills
+    NBODY_FLAG_DEBUG_WALK_ONLY = 1u << 8, /* profiling aid: traversal walks the tree and fills
                                             its source lists but skips the force arithmetic
                                             (accelerations are meaningless)                  */
+    NBODY_FLAG_DEBUG_LATE_TILES = 1u << 10 /* test aid: in the tiled scan kernels of the build
+                                            (digit passes, unique codes, leaf heads) every fourth
+                                            workgroup starts 0.3 ms late and waits are given up
+                                            after a few polls, so that waiting workgroups take
+                                            over the late ones' tiles; results are unchanged   */
 };
 
 /* The first 11 fields are Simulation<T>::Params, same order and meaning

@@ -27,6 +27,7 @@ FLAG_FIT_KEYS = 1 << 4
 FLAG_NO_UNIFORM_MASS = 1 << 5
 FLAG_DEBUG_WALK_ONLY = 1 << 8
 FLAG_DEBUG_SMALL_STACK = 1 << 9
+FLAG_DEBUG_LATE_TILES = 1 << 10
 
 IC_UNIFORM, IC_SPHERE, IC_DISK, IC_PLUMMER = 0, 1, 2, 3
 

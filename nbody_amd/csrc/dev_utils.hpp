@@ -97,13 +97,26 @@ __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t *sc
 //   bits 29..0 : value
 // The word is the whole hand-off (flag and payload travel in one naturally aligned
 // store), written and polled with relaxed agent-scope atomics, so no fence is needed.
-// Tile ids must be handed out in launch order by an atomic ticket so that every
-// predecessor of a running tile is itself running; each spin is bounded.
+//
+// Forward progress.  A tile waits for words of LOWER tiles only, so the lowest unfinished tile
+// never waits for anything that is not on its way -- provided somebody is working on it.  The
+// usual guarantee is an atomic ticket: tile ids are drawn in the order workgroups start, so
+// every predecessor of a running tile is itself running.  That counter serialises (atomics on
+// one address complete ~15 ns apart on this chip: 8 us before the last of 512 tiles may begin).
+// The two-level variants below take tile = blockIdx instead and guarantee progress by HELPING: a
+// workgroup whose wait exceeds `max_spins` polls gives the wait up (lb2_* report "stuck"),
+// looks for the lowest tile that has published nothing (lb2_lowest_unpublished) and, if there
+// is one below its own, processes THAT tile -- all of it, as its owner would -- before it starts
+// its own again.  Everything a tile publishes and writes is a pure function of the kernel's
+// input, so a tile done twice (by a helper and, later, by its late owner) stores the same values
+// twice; a status word may fall back from "inclusive prefix" to "aggregate" in between, which a
+// reader handles like any aggregate.  With workgroups started in index order -- what the
+// hardware does -- nobody ever helps; if they are not, the lowest unpublished tile is picked up
+// by whoever waits for it, whatever the start order.  Every spin is bounded.
 // ---------------------------------------------------------------------------
 constexpr uint32_t LB_AGG = 1u << 30;
 constexpr uint32_t LB_PREFIX = 2u << 30;
 constexpr uint32_t LB_MASK = (1u << 30) - 1u;
-constexpr uint32_t LB_SPIN_LIMIT = 1u << 24;
 
 __device__ __forceinline__ void lb_store(uint32_t *p, uint32_t v)
 {
@@ -114,69 +127,79 @@ __device__ __forceinline__ uint32_t lb_load(const uint32_t *p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Poll one status word until its flag is set (bounded).
-__device__ __forceinline__ uint32_t lb_wait(const uint32_t *p, uint32_t *err)
+// Poll one status word until its flag is set.  HELP: ... or max_spins polls have gone by, and a
+// word with flag 0 is returned then (the caller gives the wait up).  Not HELP (tiles numbered by
+// ticket: the owner of the word is running): waits on, and only a wait beyond any plausible
+// length ends with DEV_ERR_SPIN and an empty prefix.  The two are separate instantiations
+// because the mere possibility of giving up changes the code around every wait (measured: a
+// digit pass of 128 tiles 15.6 against 14.4 us).
+constexpr uint32_t LB_SPIN_LIMIT = 1u << 24;
+template <bool HELP>
+__device__ __forceinline__ uint32_t lb_poll(const uint32_t *p, uint32_t max_spins, uint32_t *err)
 {
     uint32_t w = lb_load(p);
     uint32_t spins = 0;
-    while ((w >> 30) == 0u) {
-        if (++spins > LB_SPIN_LIMIT) {
-            atomicOr(err, (uint32_t) DEV_ERR_SPIN);
-            return LB_PREFIX;  // give up: value 0, chain terminates
+    if constexpr (HELP) {
+        while ((w >> 30) == 0u && ++spins <= max_spins) {
+            __builtin_amdgcn_s_sleep(1);
+            w = lb_load(p);
         }
-        __builtin_amdgcn_s_sleep(1);
-        w = lb_load(p);
+    } else {
+        while ((w >> 30) == 0u) {
+            if (++spins > LB_SPIN_LIMIT) {
+                atomicOr(err, (uint32_t) DEV_ERR_SPIN);
+                return LB_PREFIX;  // give up: value 0, chain terminates
+            }
+            __builtin_amdgcn_s_sleep(1);
+            w = lb_load(p);
+        }
     }
     return w;
 }
+constexpr uint32_t LB_HELP_SPINS = 1u << 11;   // polls (a microsecond or two each) before a wait is given up
+constexpr uint32_t LB_HELP_ROUNDS = 1u << 12;  // give-ups before a workgroup reports DEV_ERR_SPIN
+constexpr uint32_t LB_TEST_SPINS = 8;          // the give-up threshold of the test mode with late workgroups
 
-// Wave-parallel look-back for ONE scanned quantity.  Must be called by all 64 lanes of
-// one wave (wave-uniform arguments).  status has one word per tile.  Returns the
-// exclusive prefix of `tile` and publishes its inclusive prefix.
-__device__ __forceinline__ uint32_t lb_exclusive_wave(uint32_t *status, int tile,
-                                                      uint32_t aggregate, uint32_t *err)
+// Lowest tile below `tile` that has published nothing yet (word q of its status row), or `tile`.
+// Called by all threads of a workgroup; s_min is one word of LDS.  Two __syncthreads().
+__device__ __forceinline__ int lb2_lowest_unpublished(const uint32_t *tile_status, int stride, int q,
+                                                      int tile, int *s_min)
 {
-    const int l = lane_id();
-    if (tile == 0) {
-        if (l == 0) lb_store(&status[0], LB_PREFIX | aggregate);
-        return 0u;
-    }
-    if (l == 0) lb_store(&status[tile], LB_AGG | aggregate);
-    uint32_t excl = 0;
-    int base = tile - 1;
-    while (true) {
-        const int t = base - l;
-        uint32_t w = LB_PREFIX;  // virtual tiles before tile 0: prefix 0
-        if (t >= 0) w = lb_wait(&status[t], err);
-        const unsigned long long pm = __ballot((w >> 30) == 2u);
-        const int first = pm ? (int) __builtin_ctzll(pm) : WAVE;  // nearest tile with a prefix
-        const uint32_t v = (l <= first) ? (w & LB_MASK) : 0u;
-        excl += wave_sum_u32(v);
-        if (pm) break;
-        base -= WAVE;
-    }
-    if (l == 0) lb_store(&status[tile], LB_PREFIX | (excl + aggregate));
-    return excl;
+    if (threadIdx.x == 0) *s_min = tile;
+    __syncthreads();
+    int lowest = tile;
+    for (int t = (int) threadIdx.x; t < tile; t += (int) blockDim.x)
+        if ((lb_load(&tile_status[(size_t) t * stride + q]) >> 30) == 0u) { lowest = t; break; }
+    if (lowest < tile) atomicMin(s_min, lowest);
+    __syncthreads();
+    return *s_min;
 }
 
-// Two-level variant for launches whose tiles are all resident at once (a few hundred to a few
-// thousand tiles on 256 CUs).  With the one-level chain above the aggregates of all tiles
-// appear at about the same moment and tile t then reads its t predecessors 64 at a time --
-// t / 64 memory round trips for the last tiles.  Here tiles form groups of LBW_GROUP: a tile
-// sums the aggregates of the earlier tiles of its group (one round trip), the last tile of a
-// group publishes the group's total, and the chained look-back runs over one word per GROUP
-// (64 groups per round trip).  Same protocol and bounds as above; all 64 lanes must call it.
+// Two levels, for launches whose tiles are all resident at once (a few hundred to a few
+// thousand tiles on 256 CUs).  With a one-level chain the aggregates of all tiles appear at
+// about the same moment and tile t then reads its t predecessors 64 at a time -- t / 64 memory
+// round trips for the last tiles.  Here tiles form groups of LBW_GROUP: a tile sums the
+// aggregates of the earlier tiles of its group (one round trip), the last tile of a group
+// publishes the group's total, and the chained look-back runs over one word per GROUP (64
+// groups per round trip).  One scanned quantity, one wave: all 64 lanes must call it
+// (wave-uniform arguments).  *stuck: a wait was given up (see above); the result is then void.
 constexpr int LBW_GROUP = 32;
 
+template <bool HELP>
 __device__ __forceinline__ uint32_t lb2_exclusive_wave(uint32_t *tile_status, uint32_t *group_status,
-                                                       int tile, uint32_t aggregate, uint32_t *err)
+                                                       int tile, uint32_t aggregate, uint32_t max_spins,
+                                                       bool *stuck, uint32_t *err)
 {
     const int l = lane_id();
     const int g = tile / LBW_GROUP, j = tile % LBW_GROUP;
+    *stuck = false;
     if (l == 0) lb_store(&tile_status[tile], LB_AGG | aggregate);
-    uint32_t v = 0;
-    if (l < j) v = lb_wait(&tile_status[g * LBW_GROUP + l], err) & LB_MASK;
-    const uint32_t in_excl = wave_sum_u32(v);
+    uint32_t v = LB_AGG;      // lanes without a predecessor: aggregate 0
+    if (l < j) v = lb_poll<HELP>(&tile_status[g * LBW_GROUP + l], max_spins, err);
+    if constexpr (HELP) {
+        if (__any((v >> 30) == 0u)) { *stuck = true; return 0u; }
+    }
+    const uint32_t in_excl = wave_sum_u32(v & LB_MASK);
     const bool leader = j == LBW_GROUP - 1;
     const uint32_t group_total = in_excl + aggregate;
     if (g == 0) {
@@ -189,7 +212,10 @@ __device__ __forceinline__ uint32_t lb2_exclusive_wave(uint32_t *tile_status, ui
     while (true) {
         const int t = base - l;
         uint32_t w = LB_PREFIX;  // virtual groups before group 0: prefix 0
-        if (t >= 0) w = lb_wait(&group_status[t], err);
+        if (t >= 0) w = lb_poll<HELP>(&group_status[t], max_spins, err);
+        if constexpr (HELP) {
+            if (__any((w >> 30) == 0u)) { *stuck = true; return 0u; }
+        }
         const unsigned long long pm = __ballot((w >> 30) == 2u);
         const int first = pm ? (int) __builtin_ctzll(pm) : WAVE;  // nearest group with a prefix
         gex += wave_sum_u32((l <= first) ? (w & LB_MASK) : 0u);
@@ -200,56 +226,21 @@ __device__ __forceinline__ uint32_t lb2_exclusive_wave(uint32_t *tile_status, ui
     return gex + in_excl;
 }
 
-// All tiles of a launch are resident at once, so inclusive prefixes spread from tile 0 at
-// LB_WINDOW tiles per memory round trip: the window, not the tile count, sets the pace.
+// The chained look-back over the group words requests LB_WINDOW of them at a time.
 #ifndef NB_LB_WINDOW
 #define NB_LB_WINDOW 8
 #endif
 constexpr int LB_WINDOW = NB_LB_WINDOW;
 
-// Look-back by a single thread for one quantity out of `stride` per tile (used by the radix
-// pass: thread d follows digit d).  The words of the 8 nearest unread predecessors are
-// requested together, so the walk costs one memory round trip per LB_WINDOW tiles, not per tile.
-__device__ __forceinline__ uint32_t lb_exclusive_thread(uint32_t *status, int stride, int q,
-                                                        int tile, uint32_t aggregate,
-                                                        uint32_t *err)
-{
-    if (tile == 0) {
-        lb_store(&status[q], LB_PREFIX | aggregate);
-        return 0u;
-    }
-    lb_store(&status[(size_t) tile * stride + q], LB_AGG | aggregate);
-    uint32_t excl = 0;
-    int t = tile - 1;
-    bool done = false;
-    while (!done && t >= 0) {
-        uint32_t w[LB_WINDOW];
-#pragma unroll
-        for (int i = 0; i < LB_WINDOW; ++i)
-            w[i] = (t - i >= 0) ? lb_load(&status[(size_t) (t - i) * stride + q]) : LB_PREFIX;
-#pragma unroll
-        for (int i = 0; i < LB_WINDOW; ++i) {
-            if (done) break;
-            uint32_t v = w[i];
-            if ((v >> 30) == 0u) v = lb_wait(&status[(size_t) (t - i) * stride + q], err);
-            excl += v & LB_MASK;
-            done = (v >> 30) == 2u;
-        }
-        t -= LB_WINDOW;
-    }
-    lb_store(&status[(size_t) tile * stride + q], LB_PREFIX | (excl + aggregate));
-    return excl;
-}
-
-// Two-level look-back by a single thread (same role as lb_exclusive_thread).  Tiles form
-// groups of LB_GROUP consecutive tiles.  A tile publishes its aggregate, sums the aggregates
+// Two-level look-back by a single thread, for one quantity out of `stride` per tile (the radix
+// pass: thread d follows digit d).  Tiles form groups of LB_GROUP consecutive tiles.  A tile publishes its aggregate, sums the aggregates
 // of the earlier tiles of its own group (they need nothing from anybody, so they are all
 // there after one round trip) and adds the exclusive prefix of its GROUP, which it finds by
 // the chained look-back over one word per group: the last tile of a group publishes the
 // group's total, looks back, and publishes the group's inclusive prefix.  When every tile of
-// a launch is resident at once (a few hundred tiles on 256 CUs) the one-level chain makes
+// a launch is resident at once (a few hundred tiles on 256 CUs) a one-level chain makes
 // tile t walk over nearly all of its t predecessors; here a tile reads at most LB_GROUP - 1
-// tile words and ntiles / LB_GROUP group words.
+// tile words and ntiles / LB_GROUP group words.  *stuck: a wait was given up; the result is void.
 // tile_status: one row of `stride` words per tile; group_status: one row per group.
 #ifndef NB_LB_GROUP
 #define NB_LB_GROUP 16
@@ -264,23 +255,34 @@ __device__ __forceinline__ void lb2_publish(uint32_t *tile_status, int stride, i
     lb_store(&tile_status[(size_t) tile * stride + q], LB_AGG | aggregate);
 }
 
+template <bool HELP>
 __device__ __forceinline__ uint32_t lb2_resolve(uint32_t *tile_status, uint32_t *group_status,
                                                 int stride, int q, int tile, uint32_t aggregate,
-                                                uint32_t *err)
+                                                uint32_t max_spins, bool *stuck, uint32_t *err)
 {
     const int g = tile / LB_GROUP, j = tile % LB_GROUP;
+    *stuck = false;
+    // (the group words are requested only when the tile words are in: asked for any earlier, with
+    // every tile of a launch in the same phase, they are mostly not there yet and cost a second
+    // round trip each)
+    uint32_t w[LB_GROUP - 1], wg[LB_WINDOW];
+    const uint32_t *row = tile_status + (size_t) g * LB_GROUP * stride + q;
+#pragma unroll
+    for (int i = 0; i < LB_GROUP - 1; ++i) w[i] = i < j ? lb_load(row + (size_t) i * stride) : LB_AGG;
     uint32_t in_excl = 0;
-    {
-        uint32_t w[LB_GROUP - 1];
-        const uint32_t *row = tile_status + (size_t) g * LB_GROUP * stride + q;
 #pragma unroll
-        for (int i = 0; i < LB_GROUP - 1; ++i) w[i] = i < j ? lb_load(row + (size_t) i * stride) : LB_AGG;
-#pragma unroll
-        for (int i = 0; i < LB_GROUP - 1; ++i) {
-            uint32_t v = w[i];
-            if ((v >> 30) == 0u) v = lb_wait(row + (size_t) i * stride, err);
-            in_excl += v & LB_MASK;
+    for (int i = 0; i < LB_GROUP - 1; ++i) {
+        uint32_t v = w[i];
+        if constexpr (HELP) {
+            if ((v >> 30) == 0u && !*stuck) v = lb_poll<true>(row + (size_t) i * stride, max_spins, err);
+            if ((v >> 30) == 0u) *stuck = true;
+        } else {
+            if ((v >> 30) == 0u) v = lb_poll<false>(row + (size_t) i * stride, max_spins, err);
         }
+        in_excl += v & LB_MASK;
+    }
+    if constexpr (HELP) {
+        if (*stuck) return 0u;
     }
     const bool leader = j == LB_GROUP - 1;
     const uint32_t group_total = in_excl + aggregate;   // meaningful for the leader only
@@ -290,15 +292,17 @@ __device__ __forceinline__ uint32_t lb2_resolve(uint32_t *tile_status, uint32_t 
         int t = g - 1;
         bool done = false;
         while (!done && t >= 0) {
-            uint32_t w[LB_WINDOW];
 #pragma unroll
             for (int i = 0; i < LB_WINDOW; ++i)
-                w[i] = (t - i >= 0) ? lb_load(&group_status[(size_t) (t - i) * stride + q]) : LB_PREFIX;
+                wg[i] = (t - i >= 0) ? lb_load(&group_status[(size_t) (t - i) * stride + q]) : LB_PREFIX;
 #pragma unroll
             for (int i = 0; i < LB_WINDOW; ++i) {
                 if (done) break;
-                uint32_t v = w[i];
-                if ((v >> 30) == 0u) v = lb_wait(&group_status[(size_t) (t - i) * stride + q], err);
+                uint32_t v = wg[i];
+                if ((v >> 30) == 0u) v = lb_poll<HELP>(&group_status[(size_t) (t - i) * stride + q], max_spins, err);
+                if constexpr (HELP) {
+                    if ((v >> 30) == 0u) { *stuck = true; return 0u; }
+                }
                 gex += v & LB_MASK;
                 done = (v >> 30) == 2u;
             }

@@ -247,12 +247,19 @@ __global__ __launch_bounds__(256) void k_tiefix_long(KeyT *k0, uint32_t *v0, Key
 // One digit pass.  n is read from n_dev when it is non-null (device-side element count,
 // used by the octree node ranking), else n_host.  IOTA: the value of element i is i.
 // inv_out (nullable): inv_out[value] = final position.
-template <typename KeyT, int ITEMS, bool IOTA>
+// Two ways of numbering the tiles (dev_utils.hpp, "Forward progress"):
+//   HELP = false: a tile draws its index from *ticket (launches of few tiles, where the queue
+//     for the counter is short); its predecessors are running, the look-back simply waits.
+//   HELP = true: tile = blockIdx; a workgroup whose look-back waits longer than help_spins polls
+//     does the lowest tile that has published nothing before it starts its own again.
+//     late_test (test aid): every fourth workgroup idles ~0.3 ms before it starts, so that its
+//     tile is taken care of by a helper first and then done a second time.
+template <typename KeyT, int ITEMS, bool IOTA, bool HELP>
 __global__ __launch_bounds__(256) void k_sort_pass(
     const KeyT *__restrict__ kin, const uint32_t *__restrict__ vin, KeyT *__restrict__ kout,
     uint32_t *__restrict__ vout, uint32_t *__restrict__ inv_out, const int32_t *n_dev,
     int n_host, int shift, const uint32_t *__restrict__ ghist, uint32_t *status,
-    uint32_t *group_status, uint32_t *ticket, uint32_t *err)
+    uint32_t *group_status, uint32_t *ticket, uint32_t help_spins, int late_test, uint32_t *err)
 {
     constexpr int NW = 4;
     constexpr int TILE = 256 * ITEMS;
@@ -260,105 +267,140 @@ __global__ __launch_bounds__(256) void k_sort_pass(
     __shared__ uint32_t s_dstart[256];
     __shared__ uint32_t s_goff[256];
     __shared__ uint32_t s_scan[NW + 1];
-    __shared__ uint32_t s_tile;
+    __shared__ int s_stuck, s_min;
     __shared__ KeyT s_keys[TILE];
     __shared__ uint32_t s_vals[TILE];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int n = n_dev ? *n_dev : n_host;
     const int ntiles = (n + TILE - 1) / TILE;
-    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
-    for (int j = tid; j < NW * 256; j += 256) (&s_whist[0][0])[j] = 0;
-    __syncthreads();
-    const int tile = (int) s_tile;
-    if (tile >= ntiles) return;
-    const int tile_base = tile * TILE;
-    const int tile_count = min(TILE, n - tile_base);
+    int own = (int) blockIdx.x;
+    if constexpr (!HELP) {
+        if (tid == 0) s_min = (int) atomicAdd(ticket, 1u);
+        __syncthreads();
+        own = s_min;
+    }
+    if (own >= ntiles) return;
+    if constexpr (HELP) {
+        if (late_test && (own & 3) == 1) {
+            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+            while (__builtin_amdgcn_s_memrealtime() - t0 < 30000ull) __builtin_amdgcn_s_sleep(32);
+        }
+    }
+    int tile = own;
+    uint32_t rounds = 0;
+    while (true) {
+        for (int j = tid; j < NW * 256; j += 256) (&s_whist[0][0])[j] = 0;
+        if (tid == 0) s_stuck = 0;
+        __syncthreads();
+        const int tile_base = tile * TILE;
+        const int tile_count = min(TILE, n - tile_base);
 
-    KeyT key[ITEMS];
-    uint32_t val[ITEMS];
-    uint32_t rank[ITEMS];
+        KeyT key[ITEMS];
+        uint32_t val[ITEMS];
+        uint32_t rank[ITEMS];
 #pragma unroll
-    for (int k = 0; k < ITEMS; ++k) {
-        const int li = w * 64 * ITEMS + k * 64 + lane;
-        const bool valid = li < tile_count;
-        key[k] = valid ? kin[tile_base + li] : ~(KeyT) 0;
-        val[k] = IOTA ? (uint32_t) (tile_base + li) : (valid ? vin[tile_base + li] : 0u);
-    }
-    // Rank every key among the keys of its wave with the same digit (stable: earlier
-    // rounds first, lower lanes first).
-#pragma unroll
-    for (int k = 0; k < ITEMS; ++k) {
-        const int li = w * 64 * ITEMS + k * 64 + lane;
-        const bool valid = li < tile_count;
-        const uint32_t d = (uint32_t) (key[k] >> shift) & 255u;
-        unsigned long long m = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const unsigned long long bb = __ballot(bit);
-            m &= bit ? bb : ~bb;
+        for (int k = 0; k < ITEMS; ++k) {
+            const int li = w * 64 * ITEMS + k * 64 + lane;
+            const bool valid = li < tile_count;
+            key[k] = valid ? kin[tile_base + li] : ~(KeyT) 0;
+            val[k] = IOTA ? (uint32_t) (tile_base + li) : (valid ? vin[tile_base + li] : 0u);
         }
-        const uint32_t r = (uint32_t) mbcnt(m);
-        const uint32_t c = (uint32_t) __popcll(m);
-        const uint32_t prev = s_whist[w][d];
-        __builtin_amdgcn_wave_barrier();
-        if (valid && r == 0) s_whist[w][d] = prev + c;
-        __builtin_amdgcn_wave_barrier();
-        rank[k] = prev + r;
-    }
-    __syncthreads();
-    // Thread d owns digit d: per-wave counts -> exclusive prefix over the waves.
-    uint32_t cnt = 0;
+        // Rank every key among the keys of its wave with the same digit (stable: earlier
+        // rounds first, lower lanes first).
 #pragma unroll
-    for (int ww = 0; ww < NW; ++ww) {
-        const uint32_t c = s_whist[ww][tid];
-        s_whist[ww][tid] = cnt;
-        cnt += c;
-    }
-    // the tile's digit counts start their way to the other tiles now; the offsets they
-    // resolve to are needed only by the write-out, after the reorder in LDS
-    lb2_publish(status, 256, tid, tile, cnt);
-    uint32_t tot;
-    const uint32_t dstart = block_excl_scan_u32<NW>(cnt, s_scan, &tot);
-    const uint32_t gbase = block_excl_scan_u32<NW>(ghist[tid], s_scan, &tot);
-    s_dstart[tid] = dstart;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < ITEMS; ++k) {
-        const int li = w * 64 * ITEMS + k * 64 + lane;
-        if (li < tile_count) {
+        for (int k = 0; k < ITEMS; ++k) {
+            const int li = w * 64 * ITEMS + k * 64 + lane;
+            const bool valid = li < tile_count;
             const uint32_t d = (uint32_t) (key[k] >> shift) & 255u;
-            const uint32_t lp = s_dstart[d] + s_whist[w][d] + rank[k];
-            s_keys[lp] = key[k];
-            s_vals[lp] = val[k];
+            unsigned long long m = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const unsigned long long bb = __ballot(bit);
+                m &= bit ? bb : ~bb;
+            }
+            const uint32_t r = (uint32_t) mbcnt(m);
+            const uint32_t c = (uint32_t) __popcll(m);
+            const uint32_t prev = s_whist[w][d];
+            __builtin_amdgcn_wave_barrier();
+            if (valid && r == 0) s_whist[w][d] = prev + c;
+            __builtin_amdgcn_wave_barrier();
+            rank[k] = prev + r;
         }
-    }
-    const uint32_t excl = lb2_resolve(status, group_status, 256, tid, tile, cnt, err);
-    s_goff[tid] = gbase + excl - dstart;  // final position = s_goff[d] + position in tile
-    __syncthreads();
-    for (int j = tid; j < tile_count; j += 256) {
-        const KeyT kk = s_keys[j];
-        const uint32_t d = (uint32_t) (kk >> shift) & 255u;
-        const uint32_t gpos = s_goff[d] + (uint32_t) j;
-        const uint32_t v = s_vals[j];
-        kout[gpos] = kk;
-        vout[gpos] = v;
-        if (inv_out) inv_out[v] = gpos;
+        __syncthreads();
+        // Thread d owns digit d: per-wave counts -> exclusive prefix over the waves.
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) {
+            const uint32_t c = s_whist[ww][tid];
+            s_whist[ww][tid] = cnt;
+            cnt += c;
+        }
+        // the tile's digit counts start their way to the other tiles now; the offsets they
+        // resolve to are needed only by the write-out, after the reorder in LDS
+        lb2_publish(status, 256, tid, tile, cnt);
+        uint32_t tot;
+        const uint32_t dstart = block_excl_scan_u32<NW>(cnt, s_scan, &tot);
+        const uint32_t gbase = block_excl_scan_u32<NW>(ghist[tid], s_scan, &tot);
+        s_dstart[tid] = dstart;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            const int li = w * 64 * ITEMS + k * 64 + lane;
+            if (li < tile_count) {
+                const uint32_t d = (uint32_t) (key[k] >> shift) & 255u;
+                const uint32_t lp = s_dstart[d] + s_whist[w][d] + rank[k];
+                s_keys[lp] = key[k];
+                s_vals[lp] = val[k];
+            }
+        }
+        bool stuck = false;
+        const uint32_t excl = lb2_resolve<HELP>(status, group_status, 256, tid, tile, cnt, help_spins, &stuck, err);
+        if (HELP && stuck) s_stuck = 1;
+        s_goff[tid] = gbase + excl - dstart;  // final position = s_goff[d] + position in tile
+        __syncthreads();
+        if (HELP && s_stuck) {
+            // some predecessor's words did not come: if a tile below this one has published
+            // nothing at all, do that one (its owner has not started), else just wait again
+            const int lowest = lb2_lowest_unpublished(status, 256, 0, tile, &s_min);
+            if (++rounds > LB_HELP_ROUNDS) {
+                if (tid == 0) atomicOr(err, (uint32_t) DEV_ERR_SPIN);
+                return;
+            }
+            tile = lowest;   // (== tile when every predecessor has published: same tile again)
+            continue;
+        }
+        for (int j = tid; j < tile_count; j += 256) {
+            const KeyT kk = s_keys[j];
+            const uint32_t d = (uint32_t) (kk >> shift) & 255u;
+            const uint32_t gpos = s_goff[d] + (uint32_t) j;
+            const uint32_t v = s_vals[j];
+            kout[gpos] = kk;
+            vout[gpos] = v;
+            if (inv_out) inv_out[v] = gpos;
+        }
+        if (!HELP || tile == own) return;
+        tile = own;   // a helped tile is done: now this workgroup's own, from the start
+        __syncthreads();   // (the write-out has read s_keys / s_goff)
     }
 }
 
 // Explicit instantiation used by the octree node ranking pass (k_tree.hip).
 void launch_rank_pass(const uint32_t *keys, uint32_t *keys_out, uint32_t *vals_out,
                       uint32_t *inv_out, const int32_t *n_dev, int n_max, const uint32_t *hist,
-                      uint32_t *status, uint32_t *ticket, uint32_t *err, hipStream_t st)
+                      uint32_t *status, bool late_test, uint32_t *err, hipStream_t st)
 {
     // status: one row of 256 words per tile, then one per group of tiles
     const int grid = (n_max + SORT_TILE - 1) / SORT_TILE;
-    hipLaunchKernelGGL((k_sort_pass<uint32_t, SORT_ITEMS, true>), dim3(grid), dim3(256), 0, st,
+    // (numbered by blockIdx: the grid is sized for the largest count, most of it leaves at once)
+    hipLaunchKernelGGL((k_sort_pass<uint32_t, SORT_ITEMS, true, true>), dim3(grid), dim3(256), 0, st,
                        keys, (const uint32_t *) nullptr, keys_out, vals_out, inv_out, n_dev, 0, 0,
-                       hist, status, status + (size_t) grid * 256, ticket, err);
+                       hist, status, status + (size_t) grid * 256, (uint32_t *) nullptr,
+                       late_test ? LB_TEST_SPINS : LB_HELP_SPINS, late_test ? 1 : 0, err);
 }
+
+constexpr int SORT_TICKET_TILES = 256;
 
 #ifndef NB_SORT_SKIP_DIGITS
 #define NB_SORT_SKIP_DIGITS 3
@@ -386,22 +428,28 @@ static hipError_t sort_impl(Sim *s)
     const int hgrid = std::min(std::max((n + 4095) / 4096, 1), NB_HIST_GRID);
     hipLaunchKernelGGL((k_sort_hist<KeyT, NPASS, P0>), dim3(hgrid), dim3(256), 0, s->stream,
                        (const KeyT *) s->keys[0], n, s->ghist);
+    // (test aid: late workgroups and an early give-up exercise the helping path of the look-back)
+    const int late = (s->p.flags & NBODY_FLAG_DEBUG_LATE_TILES) ? 1 : 0;
+    const uint32_t help = late ? LB_TEST_SPINS : LB_HELP_SPINS;
+    // numbering by ticket up to a few hundred tiles, by blockIdx (with helping) beyond: a pass of
+    // 128 tiles 14.4 against 15.6 us, of 512 tiles 25.5 against 22.4 us; the test mode always
+    // takes the second
+    const bool by_ticket = !late && tiles <= SORT_TICKET_TILES;
     int in = 0;
     for (int p = P0; p < NPASS; ++p) {
         const KeyT *kin = (const KeyT *) s->keys[in];
         KeyT *kout = (KeyT *) s->keys[in ^ 1];
         uint32_t *st = status + (size_t) (p - P0) * rows * 256;
         uint32_t *gst = st + (size_t) tiles * 256;
-        if (p == P0)
-            hipLaunchKernelGGL((k_sort_pass<KeyT, SORT_ITEMS, true>), dim3(tiles), dim3(256), 0,
-                               s->stream, kin, (const uint32_t *) nullptr, kout, s->vals[in ^ 1],
-                               (uint32_t *) nullptr, (const int32_t *) nullptr, n, 8 * p,
-                               s->ghist + p * 256, st, gst, tickets + p, &s->counts->err);
-        else
-            hipLaunchKernelGGL((k_sort_pass<KeyT, SORT_ITEMS, false>), dim3(tiles), dim3(256), 0,
-                               s->stream, kin, (const uint32_t *) s->vals[in], kout,
-                               s->vals[in ^ 1], (uint32_t *) nullptr, (const int32_t *) nullptr, n,
-                               8 * p, s->ghist + p * 256, st, gst, tickets + p, &s->counts->err);
+        const uint32_t *vin = p == P0 ? (const uint32_t *) nullptr : (const uint32_t *) s->vals[in];
+#define NB_PASS(IOTA, HELP)                                                                          \
+        hipLaunchKernelGGL((k_sort_pass<KeyT, SORT_ITEMS, IOTA, HELP>), dim3(tiles), dim3(256), 0,     \
+                           s->stream, kin, vin, kout, s->vals[in ^ 1], (uint32_t *) nullptr,           \
+                           (const int32_t *) nullptr, n, 8 * p, s->ghist + p * 256, st, gst,           \
+                           tickets + p, help, late, &s->counts->err)
+        if (p == P0) { if (by_ticket) NB_PASS(true, false); else NB_PASS(true, true); }
+        else         { if (by_ticket) NB_PASS(false, false); else NB_PASS(false, true); }
+#undef NB_PASS
         in ^= 1;
     }
     s->sorted_buf = in;

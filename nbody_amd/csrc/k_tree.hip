@@ -20,7 +20,7 @@ namespace nb {
 
 void launch_rank_pass(const uint32_t *keys, uint32_t *keys_out, uint32_t *vals_out,
                       uint32_t *inv_out, const int32_t *n_dev, int n_max, const uint32_t *hist,
-                      uint32_t *status, uint32_t *ticket, uint32_t *err, hipStream_t st);
+                      uint32_t *status, bool late_test, uint32_t *err, hipStream_t st);
 
 constexpr int DEPTH_ROW = 32;      // words of a workgroup's depth counts: a 63-bit key has 22 depths
 constexpr int DEPTH_GRID = 2048;   // workgroups of k_depth
@@ -81,52 +81,99 @@ __device__ __forceinline__ uint32_t striped_offsets(const unsigned long long (&b
     return *s_tot;
 }
 
-template <typename KeyT, int ITEMS>
+// HELP as in k_sort_pass: false = tiles numbered by ticket, the look-back simply waits; true =
+// tile = blockIdx, and a workgroup whose look-back gives a wait up does the lowest tile that has
+// published nothing, then its own again (help_spins / late_test: see there).
+__device__ __forceinline__ void late_start(int late_test, int own)
+{
+    if (late_test && (own & 3) == 1) {
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+        while (__builtin_amdgcn_s_memrealtime() - t0 < 30000ull) __builtin_amdgcn_s_sleep(32);
+    }
+}
+
+template <typename KeyT, int ITEMS, bool HELP>
 __global__ __launch_bounds__(SCAN_THREADS) void k_unique(const KeyT *__restrict__ sorted, int n,
                                                          KeyT *__restrict__ unique,
                                                          int32_t *__restrict__ first_pt,
                                                          Counts *counts, uint32_t *status,
-                                                         uint32_t *group_status, uint32_t *ticket)
+                                                         uint32_t *group_status, uint32_t *ticket,
+                                                         uint32_t help_spins, int late_test)
 {
     __shared__ uint32_t s_cnt[ITEMS * 4];
     __shared__ uint32_t s_bcast[3];
+    __shared__ int s_stuck, s_min;
+    __shared__ KeyT s_last[ITEMS * 4 + 1];
+    static_assert(SCAN_THREADS == 256, "four waves per tile row");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) s_bcast[0] = atomicAdd(ticket, 1u);
-    __syncthreads();
-    const int tile = (int) s_bcast[0];
     constexpr int TILE = SCAN_THREADS * ITEMS;
     const int ntiles = (n + TILE - 1) / TILE;
-    if (tile >= ntiles) return;
-    const int tile_base = tile * TILE;
-    KeyT k[ITEMS];
-    unsigned long long bal[ITEMS];
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const int gi = tile_base + j * SCAN_THREADS + tid;
-        const int ci = min(gi, n - 1);
-        k[j] = sorted[ci];
-        const KeyT prev = sorted[max(ci - 1, 0)];       // (the neighbouring lane's line: a cache hit)
-        bal[j] = __ballot(gi < n && (gi == 0 || k[j] != prev));
+    int own = (int) blockIdx.x;
+    if constexpr (!HELP) {
+        if (tid == 0) s_min = (int) atomicAdd(ticket, 1u);
+        __syncthreads();
+        own = s_min;
     }
-    const uint32_t tot = striped_offsets<ITEMS>(bal, s_cnt, &s_bcast[2]);
-    if (tid < 64) {
-        const uint32_t te = lb2_exclusive_wave(status, group_status, tile, tot, &counts->err);
-        if (tid == 0) s_bcast[1] = te;
-    }
-    __syncthreads();
-    const uint32_t tile_excl = s_bcast[1];
+    if (own >= ntiles) return;
+    if constexpr (HELP) late_start(late_test, own);
+    int tile = own;
+    uint32_t rounds = 0;
+    while (true) {
+        const int tile_base = tile * TILE;
+        // Every key is loaded once, all loads in flight together.  A key's predecessor is the
+        // neighbouring lane's key; lane 0 of a wave takes it from the last lane of the wave before
+        // (same item), wave 0 from the last wave of the item before, through s_last -- only the
+        // key before the tile comes from memory.
+        KeyT k[ITEMS];
+        unsigned long long bal[ITEMS];
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        if ((bal[j] >> lane) & 1ull) {
-            const uint32_t pos = tile_excl + s_cnt[j * 4 + w] + (uint32_t) mbcnt(bal[j]);
-            unique[pos] = k[j];
-            first_pt[pos] = tile_base + j * SCAN_THREADS + tid;
+        for (int j = 0; j < ITEMS; ++j) k[j] = sorted[min(tile_base + j * SCAN_THREADS + tid, n - 1)];
+        if (tid == 0) s_last[0] = sorted[max(tile_base - 1, 0)];
+        if (lane == 63) {
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) s_last[1 + j * 4 + w] = k[j];
         }
-    }
-    if (tile == ntiles - 1 && tid == 0) {
-        const int U = (int) (tile_excl + tot);
-        counts->U = U;
-        first_pt[U] = n;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int gi = tile_base + j * SCAN_THREADS + tid;
+            KeyT prev = (KeyT) __shfl_up((unsigned long long) k[j], 1, 64);
+            if (lane == 0) prev = s_last[j * 4 + w];
+            bal[j] = __ballot(gi < n && (gi == 0 || k[j] != prev));
+        }
+        const uint32_t tot = striped_offsets<ITEMS>(bal, s_cnt, &s_bcast[2]);
+        if (tid < 64) {
+            bool stuck = false;
+            const uint32_t te = lb2_exclusive_wave<HELP>(status, group_status, tile, tot, help_spins, &stuck, &counts->err);
+            if (tid == 0) { s_bcast[1] = te; s_stuck = stuck ? 1 : 0; }
+        }
+        __syncthreads();
+        if (HELP && s_stuck) {
+            const int lowest = lb2_lowest_unpublished(status, 1, 0, tile, &s_min);
+            if (++rounds > LB_HELP_ROUNDS) {
+                if (tid == 0) atomicOr(&counts->err, (uint32_t) DEV_ERR_SPIN);
+                return;
+            }
+            tile = lowest;
+            continue;
+        }
+        const uint32_t tile_excl = s_bcast[1];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            if ((bal[j] >> lane) & 1ull) {
+                const uint32_t pos = tile_excl + s_cnt[j * 4 + w] + (uint32_t) mbcnt(bal[j]);
+                unique[pos] = k[j];
+                first_pt[pos] = tile_base + j * SCAN_THREADS + tid;
+            }
+        }
+        if (tile == ntiles - 1 && tid == 0) {
+            const int U = (int) (tile_excl + tot);
+            counts->U = U;
+            first_pt[U] = n;
+        }
+        if (!HELP || tile == own) return;
+        tile = own;
+        __syncthreads();   // (s_cnt / s_bcast / s_last are rewritten by the next round)
     }
 }
 
@@ -176,65 +223,83 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_leaves(const KeyT *__restrict_
                                                          int max_codes, int32_t *__restrict__ lfc,
                                                          KeyT *__restrict__ leaf_key,
                                                          Counts *counts, uint32_t *status,
-                                                         uint32_t *group_status, uint32_t *ticket)
+                                                         uint32_t *group_status, uint32_t help_spins,
+                                                         int late_test)
 {
     __shared__ uint32_t s_cnt[LEAF_ITEMS * 4];
     __shared__ uint32_t s_bcast[3];
+    __shared__ int s_stuck, s_min;
     __shared__ KeyT s_keys[LEAF_TILE + 2 * LEAF_HALO];
     const int tid = threadIdx.x;
     const int U = counts->U;
-    if (tid == 0) s_bcast[0] = atomicAdd(ticket, 1u);
-    __syncthreads();
-    const int tile = (int) s_bcast[0];
     const int ntiles = (U + LEAF_TILE - 1) / LEAF_TILE;
-    if (tile >= ntiles) return;
+    const int own = (int) blockIdx.x;
+    if (own >= ntiles) return;
+    late_start(late_test, own);
     const bool single = U <= max_codes;  // whole set fits one leaf (undefined in the reference)
-    // The flag of code i looks at codes i - max_codes .. i + max_codes - 1 in a chain of dependent
-    // reads: stage the tile and a halo in LDS so that the chain runs at LDS latency.
-    const int s_lo = tile * LEAF_TILE - LEAF_HALO;
-    for (int j = tid; j < LEAF_TILE + 2 * LEAF_HALO; j += SCAN_THREADS) {
-        const int g = s_lo + j;
-        if (g >= 0 && g < U) s_keys[j] = unique[g];
-    }
-    __syncthreads();
-    const bool staged = max_codes <= LEAF_HALO;
-    auto at = [&](int j) -> KeyT {
-        const int r = j - s_lo;
-        return (staged && r >= 0 && r < LEAF_TILE + 2 * LEAF_HALO) ? s_keys[r] : unique[j];
-    };
-
-    // striped over the tile (thread t takes codes t, t + 256, ...): the lanes of a wave then
-    // probe consecutive LDS words at every step of the search
-    unsigned long long bal[LEAF_ITEMS];
-#pragma unroll
-    for (int j = 0; j < LEAF_ITEMS; ++j) {
-        const int i = tile * LEAF_TILE + j * SCAN_THREADS + tid;
-        bool f = false;
-        if (i < U) f = single ? (i == 0) : leaf_head_flag<KeyT>(at, i, U, max_codes);
-        bal[j] = __ballot(f);
-    }
-    const uint32_t tot = striped_offsets<LEAF_ITEMS>(bal, s_cnt, &s_bcast[2]);
-    if (tid < 64) {
-        const uint32_t te = lb2_exclusive_wave(status, group_status, tile, tot, &counts->err);
-        if (tid == 0) s_bcast[1] = te;
-    }
-    __syncthreads();
-    const uint32_t tile_excl = s_bcast[1];
-    const int lane = tid & 63, w = tid >> 6;
-#pragma unroll
-    for (int j = 0; j < LEAF_ITEMS; ++j) {
-        if ((bal[j] >> lane) & 1ull) {
-            const int i = tile * LEAF_TILE + j * SCAN_THREADS + tid;
-            const uint32_t pos = tile_excl + s_cnt[j * 4 + w] + (uint32_t) mbcnt(bal[j]);
-            lfc[pos] = i;
-            leaf_key[pos] = at(i);
+    int tile = own;
+    uint32_t rounds = 0;
+    while (true) {
+        // The flag of code i looks at codes i - max_codes .. i + max_codes - 1 in a chain of dependent
+        // reads: stage the tile and a halo in LDS so that the chain runs at LDS latency.
+        const int s_lo = tile * LEAF_TILE - LEAF_HALO;
+        for (int j = tid; j < LEAF_TILE + 2 * LEAF_HALO; j += SCAN_THREADS) {
+            const int g = s_lo + j;
+            if (g >= 0 && g < U) s_keys[j] = unique[g];
         }
-    }
-    if (tile == ntiles - 1 && tid == 0) {
-        const int M = (int) (tile_excl + tot);
-        counts->M = M;
-        counts->n_bt = 2 * M - 1;
-        lfc[M] = U;
+        __syncthreads();
+        const bool staged = max_codes <= LEAF_HALO;
+        auto at = [&](int j) -> KeyT {
+            const int r = j - s_lo;
+            return (staged && r >= 0 && r < LEAF_TILE + 2 * LEAF_HALO) ? s_keys[r] : unique[j];
+        };
+
+        // striped over the tile (thread t takes codes t, t + 256, ...): the lanes of a wave then
+        // probe consecutive LDS words at every step of the search
+        unsigned long long bal[LEAF_ITEMS];
+#pragma unroll
+        for (int j = 0; j < LEAF_ITEMS; ++j) {
+            const int i = tile * LEAF_TILE + j * SCAN_THREADS + tid;
+            bool f = false;
+            if (i < U) f = single ? (i == 0) : leaf_head_flag<KeyT>(at, i, U, max_codes);
+            bal[j] = __ballot(f);
+        }
+        const uint32_t tot = striped_offsets<LEAF_ITEMS>(bal, s_cnt, &s_bcast[2]);
+        if (tid < 64) {
+            bool stuck = false;
+            const uint32_t te = lb2_exclusive_wave<true>(status, group_status, tile, tot, help_spins, &stuck, &counts->err);
+            if (tid == 0) { s_bcast[1] = te; s_stuck = stuck ? 1 : 0; }
+        }
+        __syncthreads();
+        if (s_stuck) {
+            const int lowest = lb2_lowest_unpublished(status, 1, 0, tile, &s_min);
+            if (++rounds > LB_HELP_ROUNDS) {
+                if (tid == 0) atomicOr(&counts->err, (uint32_t) DEV_ERR_SPIN);
+                return;
+            }
+            tile = lowest;
+            continue;
+        }
+        const uint32_t tile_excl = s_bcast[1];
+        const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+        for (int j = 0; j < LEAF_ITEMS; ++j) {
+            if ((bal[j] >> lane) & 1ull) {
+                const int i = tile * LEAF_TILE + j * SCAN_THREADS + tid;
+                const uint32_t pos = tile_excl + s_cnt[j * 4 + w] + (uint32_t) mbcnt(bal[j]);
+                lfc[pos] = i;
+                leaf_key[pos] = at(i);
+            }
+        }
+        if (tile == ntiles - 1 && tid == 0) {
+            const int M = (int) (tile_excl + tot);
+            counts->M = M;
+            counts->n_bt = 2 * M - 1;
+            lfc[M] = U;
+        }
+        if (tile == own) return;
+        tile = own;
+        __syncthreads();   // (s_keys / s_cnt / s_bcast are rewritten by the next round)
     }
 }
 
@@ -481,21 +546,28 @@ static hipError_t build_impl(Sim *s)
     if (e != hipSuccess) return e;
     s->build_scratch_zeroed = false;
     const KeyT *sorted = (const KeyT *) s->keys[s->sorted_buf];
-    // (a tile costs its place in the queue for the ticket, ~15 ns, whatever its size: large
-    // inputs take tiles of 8192 keys, small ones keep 4096 so that there are enough of them)
-    if (n >= (1 << 20))
-        hipLaunchKernelGGL((k_unique<KeyT, 2 * SCAN_ITEMS>), dim3((n + 2 * SCAN_TILE - 1) / (2 * SCAN_TILE)),
-                           dim3(SCAN_THREADS), 0, st, sorted, n, (KeyT *) s->unique, s->first_pt, s->counts,
-                           s->scan_status, s->scan_status + s->max_scan_tiles, s->tickets + 0);
-    else
-        hipLaunchKernelGGL((k_unique<KeyT, SCAN_ITEMS>), dim3((n + SCAN_TILE - 1) / SCAN_TILE), dim3(SCAN_THREADS),
-                           0, st, sorted, n, (KeyT *) s->unique, s->first_pt, s->counts, s->scan_status,
-                           s->scan_status + s->max_scan_tiles, s->tickets + 0);
+    // (test aid: late workgroups and an early give-up exercise the helping path of the look-back)
+    const int late = (s->p.flags & NBODY_FLAG_DEBUG_LATE_TILES) ? 1 : 0;
+    const uint32_t help = late ? LB_TEST_SPINS : LB_HELP_SPINS;
+    // Tiles of 8192 keys from a million keys on (fewer tiles to number and to look back over),
+    // of 4096 below so that there are enough of them; numbered by ticket up to 4 M keys, by
+    // blockIdx with helping beyond (and in the test mode).
+    {
+        uint32_t *st0 = s->scan_status, *gst0 = s->scan_status + s->max_scan_tiles, *tk = s->tickets + 0;
+#define NB_UNIQUE(IT, HELP)                                                                             \
+        hipLaunchKernelGGL((k_unique<KeyT, IT, HELP>), dim3((n + SCAN_THREADS * IT - 1) / (SCAN_THREADS * IT)), \
+                           dim3(SCAN_THREADS), 0, st, sorted, n, (KeyT *) s->unique, s->first_pt, s->counts, \
+                           st0, gst0, tk, help, late)
+        const bool big = n >= (1 << 20), by_help = late || n > (1 << 22);
+        if (big) { if (by_help) NB_UNIQUE(2 * SCAN_ITEMS, true); else NB_UNIQUE(2 * SCAN_ITEMS, false); }
+        else     { if (by_help) NB_UNIQUE(SCAN_ITEMS, true); else NB_UNIQUE(SCAN_ITEMS, false); }
+#undef NB_UNIQUE
+    }
     const int leaf_grid = (n + LEAF_TILE - 1) / LEAF_TILE;
     hipLaunchKernelGGL(k_leaves<KeyT>, dim3(leaf_grid), dim3(SCAN_THREADS), 0, st,
                        (const KeyT *) s->unique, s->p.max_num_codes_per_leaf, s->lfc,
                        (KeyT *) s->leaf_key, s->counts, s->scan_status + 2 * (size_t) s->max_scan_tiles,
-                       s->scan_status + 3 * (size_t) s->max_scan_tiles, s->tickets + 1);
+                       s->scan_status + 3 * (size_t) s->max_scan_tiles, help, late);
     const int node_grid = std::min((n + 255) / 256, 2048);
     hipLaunchKernelGGL(k_radix<KeyT>, dim3(node_grid), dim3(256), 0, st,
                        (const KeyT *) s->leaf_key, s->counts, s->rt_pd, s->rt_level, s->rt_lb,
@@ -507,7 +579,7 @@ static hipError_t build_impl(Sim *s)
     hipLaunchKernelGGL(k_depth, dim3(depth_grid), dim3(256), 0, st, s->counts, s->rt_pd,
                        s->depth_key, s->dhist, many ? s->depth_rows : (uint32_t *) nullptr, s->tickets + 9);
     launch_rank_pass(s->depth_key, s->o_depth, s->bfs, s->octid, &s->counts->n_bt, 2 * n,
-                     s->dhist, s->rank_status, s->tickets + 2, &s->counts->err, st);
+                     s->dhist, s->rank_status, late != 0, &s->counts->err, st);
     hipLaunchKernelGGL(k_emit, dim3(node_grid), dim3(256), 0, st, s->counts, s->p.domain_size,
                        (const float *) s->keybox, s->dhist, s->bfs, s->octid, s->rt_pd, s->rt_level, s->rt_lb, s->rt_le,
                        s->rt_left, s->rt_right, s->lfc, s->first_pt, s->o_first_child,
