@@ -679,9 +679,10 @@ def main():
                                        f"{BUILD_BYTES_PER_PARTICLE[21]} with 63-bit keys); 2.6 TB/s at 16.7 M "
                                        "particles. Only kick-drift and permute stream at the chip's rate; a digit "
                                        "pass is a chain per tile (ticket, load, rank, look-back, write) with two "
-                                       "workgroups per CU, no unit busy more than a third of the time, and the "
-                                       "same-address ticket atomics of every ticketed kernel complete 15 ns apart "
-                                       "(profiles/r3_sort_pass_experiments.txt); the waves of the tree and "
+                                       "workgroups per CU, no unit busy more than a third of the time "
+                                       "(profiles/r3_sort_pass_experiments.txt; launches of many tiles number them by "
+                                       "workgroup index with helping instead of a same-address ticket atomic, which "
+                                       "completes 15 ns apart); the waves of the tree and "
                                        "centre-of-mass kernels wait 60-85 % of their cycles on dependent loads "
                                        "(profiles/r3_build_kernels_pmc_2M_16M.txt)"},
         }
