@@ -103,8 +103,9 @@ __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t *sc
 // usual guarantee is an atomic ticket: tile ids are drawn in the order workgroups start, so
 // every predecessor of a running tile is itself running.  That counter serialises (atomics on
 // one address complete ~15 ns apart on this chip: 8 us before the last of 512 tiles may begin).
-// The two-level variants below take tile = blockIdx instead and guarantee progress by HELPING: a
-// workgroup whose wait exceeds `max_spins` polls gives the wait up (lb2_* report "stuck"),
+// Kernels instantiated with HELP = true take tile = blockIdx instead and guarantee progress by
+// HELPING: a workgroup whose wait exceeds `max_spins` polls gives the wait up (lb2_*<true> report
+// "stuck"),
 // looks for the lowest tile that has published nothing (lb2_lowest_unpublished) and, if there
 // is one below its own, processes THAT tile -- all of it, as its owner would -- before it starts
 // its own again.  Everything a tile publishes and writes is a pure function of the kernel's
@@ -112,7 +113,9 @@ __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t *sc
 // twice; a status word may fall back from "inclusive prefix" to "aggregate" in between, which a
 // reader handles like any aggregate.  With workgroups started in index order -- what the
 // hardware does -- nobody ever helps; if they are not, the lowest unpublished tile is picked up
-// by whoever waits for it, whatever the start order.  Every spin is bounded.
+// by whoever waits for it, whatever the start order.  Every spin is bounded.  Launches of few
+// tiles keep the ticket (HELP = false): the queue is short there, and the look-back that cannot
+// give up is about a microsecond faster per launch.
 // ---------------------------------------------------------------------------
 constexpr uint32_t LB_AGG = 1u << 30;
 constexpr uint32_t LB_PREFIX = 2u << 30;

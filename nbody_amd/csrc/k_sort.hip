@@ -7,7 +7,8 @@
 // Structure (8-bit digits, P = ceil(key_bits/8) passes):
 //   k_sort_hist : one read of the keys, all P digit histograms at once (LDS atomics, then
 //                 one global atomic per non-empty bin per workgroup).
-//   k_sort_pass : one launch per digit.  A workgroup takes a tile by atomic ticket, ranks
+//   k_sort_pass : one launch per digit.  A workgroup takes a tile (its own index, or a ticket
+//                 in launches of few tiles: see the kernel), ranks
 //                 its keys with wave64 ballot matching, publishes the tile's 256 digit
 //                 counts, reorders the tile in LDS by digit, resolves the counts' global
 //                 offsets by the two-level look-back over the earlier tiles (dev_utils.hpp)
