@@ -27,25 +27,34 @@
 #ifndef NB_HIST_GRID
 #define NB_HIST_GRID 256
 #endif
+#ifndef NB_HIST_THREADS
+#define NB_HIST_THREADS 1024
+#endif
+#ifndef NB_HIST_KEYS
+#define NB_HIST_KEYS 8
+#endif
 namespace nb {
 
 // digits P0 .. NPASS-1 (ghist keeps one row of 256 per digit, rows below P0 stay zero)
 template <typename KeyT, int NPASS, int P0>
-__global__ __launch_bounds__(256) void k_sort_hist(const KeyT *__restrict__ keys, int n,
-                                                   uint32_t *__restrict__ ghist)
+__global__ __launch_bounds__(NB_HIST_THREADS) void k_sort_hist(const KeyT *__restrict__ keys, int n,
+                                                               uint32_t *__restrict__ ghist)
 {
+    constexpr int HT = NB_HIST_THREADS;
     __shared__ uint32_t h[NPASS * 256];
-    for (int j = threadIdx.x + P0 * 256; j < NPASS * 256; j += 256) h[j] = 0;
+    for (int j = threadIdx.x + P0 * 256; j < NPASS * 256; j += HT) h[j] = 0;
     __syncthreads();
-    // HK consecutive keys per thread and round (few workgroups: the hot bins take one global
-    // atomic per workgroup; many keys in flight per thread instead).  The keys arrive in the
+    // HK consecutive keys per thread and round, in few but large workgroups: the hot bins take one
+    // global atomic per workgroup, so their number stays at one per CU, and 16 waves per CU keep
+    // enough loads in flight (256-thread workgroups of 16 keys per thread: 17.5 us at 2 M keys,
+    // 84 us at 16.7 M; 1024 threads of 8 keys: 12 and 40).  The keys arrive in the
     // previous step's order, so their upper digits repeat from one key to the next: a wave
     // whose HK x 64 keys agree in a digit adds them with one LDS atomic, and a thread's equal
     // neighbours share one otherwise.
-    constexpr int HK = 16;
-    const int stride = gridDim.x * 256 * HK;
+    constexpr int HK = NB_HIST_KEYS;
+    const int stride = gridDim.x * HT * HK;
     const int lane = threadIdx.x & 63;
-    for (int i0 = (blockIdx.x * 256 + threadIdx.x) * HK; i0 < n; i0 += stride) {
+    for (int i0 = (blockIdx.x * HT + threadIdx.x) * HK; i0 < n; i0 += stride) {
         KeyT k[HK];
         const int cntv = min(HK, n - i0);
         if (cntv == HK) {
@@ -81,7 +90,7 @@ __global__ __launch_bounds__(256) void k_sort_hist(const KeyT *__restrict__ keys
         }
     }
     __syncthreads();
-    for (int j = threadIdx.x + P0 * 256; j < NPASS * 256; j += 256) {
+    for (int j = threadIdx.x + P0 * 256; j < NPASS * 256; j += HT) {
         const uint32_t c = h[j];
         if (c) atomicAdd(&ghist[j], c);
     }
@@ -426,8 +435,8 @@ static hipError_t sort_impl(Sim *s)
     // layout of the zeroed block: ghist[8*256] | tickets[8] (+pad to 16) | status[P][rows][256]
     uint32_t *tickets = s->ghist + 8 * 256;
     uint32_t *status = tickets + 16;
-    const int hgrid = std::min(std::max((n + 4095) / 4096, 1), NB_HIST_GRID);
-    hipLaunchKernelGGL((k_sort_hist<KeyT, NPASS, P0>), dim3(hgrid), dim3(256), 0, s->stream,
+    const int hgrid = std::min(std::max((n + NB_HIST_THREADS * NB_HIST_KEYS - 1) / (NB_HIST_THREADS * NB_HIST_KEYS), 1), NB_HIST_GRID);
+    hipLaunchKernelGGL((k_sort_hist<KeyT, NPASS, P0>), dim3(hgrid), dim3(NB_HIST_THREADS), 0, s->stream,
                        (const KeyT *) s->keys[0], n, s->ghist);
     // (test aid: late workgroups and an early give-up exercise the helping path of the look-back)
     const int late = (s->p.flags & NBODY_FLAG_DEBUG_LATE_TILES) ? 1 : 0;
