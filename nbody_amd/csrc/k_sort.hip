@@ -265,14 +265,16 @@ __global__ __launch_bounds__(256) void k_tiefix_long(KeyT *k0, uint32_t *v0, Key
 //     late_test (test aid): every fourth workgroup idles ~0.3 ms before it starts, so that its
 //     tile is taken care of by a helper first and then done a second time.
 template <typename KeyT, int ITEMS, bool IOTA, bool HELP>
-__global__ __launch_bounds__(256) void k_sort_pass(
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_pass(
     const KeyT *__restrict__ kin, const uint32_t *__restrict__ vin, KeyT *__restrict__ kout,
     uint32_t *__restrict__ vout, uint32_t *__restrict__ inv_out, const int32_t *n_dev,
     int n_host, int shift, const uint32_t *__restrict__ ghist, uint32_t *status,
     uint32_t *group_status, uint32_t *ticket, uint32_t help_spins, int late_test, uint32_t *err)
 {
-    constexpr int NW = 4;
-    constexpr int TILE = 256 * ITEMS;
+    // NW waves share a tile: its 256 digits are looked after by the first 256 threads
+    constexpr int NW = SORT_WAVES, NT = SORT_THREADS;
+    constexpr int TILE = NT * ITEMS;
+    static_assert(NT >= 256, "one thread per digit");
     __shared__ uint32_t s_whist[NW][256];
     __shared__ uint32_t s_dstart[256];
     __shared__ uint32_t s_goff[256];
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(256) void k_sort_pass(
     int tile = own;
     uint32_t rounds = 0;
     while (true) {
-        for (int j = tid; j < NW * 256; j += 256) (&s_whist[0][0])[j] = 0;
+        for (int j = tid; j < NW * 256; j += NT) (&s_whist[0][0])[j] = 0;
         if (tid == 0) s_stuck = 0;
         __syncthreads();
         const int tile_base = tile * TILE;
@@ -340,20 +342,23 @@ __global__ __launch_bounds__(256) void k_sort_pass(
         }
         __syncthreads();
         // Thread d owns digit d: per-wave counts -> exclusive prefix over the waves.
+        const bool digit = tid < 256;
         uint32_t cnt = 0;
+        if (digit) {
 #pragma unroll
-        for (int ww = 0; ww < NW; ++ww) {
-            const uint32_t c = s_whist[ww][tid];
-            s_whist[ww][tid] = cnt;
-            cnt += c;
+            for (int ww = 0; ww < NW; ++ww) {
+                const uint32_t c = s_whist[ww][tid];
+                s_whist[ww][tid] = cnt;
+                cnt += c;
+            }
+            // the tile's digit counts start their way to the other tiles now; the offsets they
+            // resolve to are needed only by the write-out, after the reorder in LDS
+            lb2_publish(status, 256, tid, tile, cnt);
         }
-        // the tile's digit counts start their way to the other tiles now; the offsets they
-        // resolve to are needed only by the write-out, after the reorder in LDS
-        lb2_publish(status, 256, tid, tile, cnt);
         uint32_t tot;
         const uint32_t dstart = block_excl_scan_u32<NW>(cnt, s_scan, &tot);
-        const uint32_t gbase = block_excl_scan_u32<NW>(ghist[tid], s_scan, &tot);
-        s_dstart[tid] = dstart;
+        const uint32_t gbase = block_excl_scan_u32<NW>(digit ? ghist[tid] : 0u, s_scan, &tot);
+        if (digit) s_dstart[tid] = dstart;
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < ITEMS; ++k) {
@@ -366,9 +371,11 @@ __global__ __launch_bounds__(256) void k_sort_pass(
             }
         }
         bool stuck = false;
-        const uint32_t excl = lb2_resolve<HELP>(status, group_status, 256, tid, tile, cnt, help_spins, &stuck, err);
-        if (HELP && stuck) s_stuck = 1;
-        s_goff[tid] = gbase + excl - dstart;  // final position = s_goff[d] + position in tile
+        if (digit) {
+            const uint32_t excl = lb2_resolve<HELP>(status, group_status, 256, tid, tile, cnt, help_spins, &stuck, err);
+            if (HELP && stuck) s_stuck = 1;
+            s_goff[tid] = gbase + excl - dstart;  // final position = s_goff[d] + position in tile
+        }
         __syncthreads();
         if (HELP && s_stuck) {
             // some predecessor's words did not come: if a tile below this one has published
@@ -381,7 +388,7 @@ __global__ __launch_bounds__(256) void k_sort_pass(
             tile = lowest;   // (== tile when every predecessor has published: same tile again)
             continue;
         }
-        for (int j = tid; j < tile_count; j += 256) {
+        for (int j = tid; j < tile_count; j += NT) {
             const KeyT kk = s_keys[j];
             const uint32_t d = (uint32_t) (kk >> shift) & 255u;
             const uint32_t gpos = s_goff[d] + (uint32_t) j;
@@ -404,7 +411,7 @@ void launch_rank_pass(const uint32_t *keys, uint32_t *keys_out, uint32_t *vals_o
     // status: one row of 256 words per tile, then one per group of tiles
     const int grid = (n_max + SORT_TILE - 1) / SORT_TILE;
     // (numbered by blockIdx: the grid is sized for the largest count, most of it leaves at once)
-    hipLaunchKernelGGL((k_sort_pass<uint32_t, SORT_ITEMS, true, true>), dim3(grid), dim3(256), 0, st,
+    hipLaunchKernelGGL((k_sort_pass<uint32_t, SORT_ITEMS, true, true>), dim3(grid), dim3(SORT_THREADS), 0, st,
                        keys, (const uint32_t *) nullptr, keys_out, vals_out, inv_out, n_dev, 0, 0,
                        hist, status, status + (size_t) grid * 256, (uint32_t *) nullptr,
                        late_test ? LB_TEST_SPINS : LB_HELP_SPINS, late_test ? 1 : 0, err);
@@ -453,7 +460,7 @@ static hipError_t sort_impl(Sim *s)
         uint32_t *gst = st + (size_t) tiles * 256;
         const uint32_t *vin = p == P0 ? (const uint32_t *) nullptr : (const uint32_t *) s->vals[in];
 #define NB_PASS(IOTA, HELP)                                                                          \
-        hipLaunchKernelGGL((k_sort_pass<KeyT, SORT_ITEMS, IOTA, HELP>), dim3(tiles), dim3(256), 0,     \
+        hipLaunchKernelGGL((k_sort_pass<KeyT, SORT_ITEMS, IOTA, HELP>), dim3(tiles), dim3(SORT_THREADS), 0, \
                            s->stream, kin, vin, kout, s->vals[in ^ 1], (uint32_t *) nullptr,           \
                            (const int32_t *) nullptr, n, 8 * p, s->ghist + p * 256, st, gst,           \
                            tickets + p, help, late, &s->counts->err)

@@ -10,10 +10,14 @@
 namespace nb {
 
 // Work distribution constants shared by host sizing code and kernels.
-constexpr int SORT_THREADS = 256;
-#ifndef NB_SORT_ITEMS
-#define NB_SORT_ITEMS 16
+#ifndef NB_SORT_WAVES
+#define NB_SORT_WAVES 8
 #endif
+#ifndef NB_SORT_ITEMS
+#define NB_SORT_ITEMS (64 / NB_SORT_WAVES)
+#endif
+constexpr int SORT_WAVES = NB_SORT_WAVES;           // waves per workgroup of a radix tile
+constexpr int SORT_THREADS = 64 * SORT_WAVES;
 constexpr int SORT_ITEMS = NB_SORT_ITEMS;           // keys per thread per radix tile
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;
 #ifndef NB_LB_GROUP
