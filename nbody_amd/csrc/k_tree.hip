@@ -211,14 +211,10 @@ __device__ __forceinline__ bool leaf_head_flag(At at, int i, int U, int max_code
     return probe < U && (at(probe) >> sh) == pre;
 }
 
-#ifndef NB_LEAF_ITEMS
-#define NB_LEAF_ITEMS 8
-#endif
-constexpr int LEAF_ITEMS = NB_LEAF_ITEMS;
-constexpr int LEAF_TILE = SCAN_THREADS * LEAF_ITEMS;
+static_assert(SCAN_TILE >= 1024, "the look-back rows are sized for tiles of at least 1024 (max_scan_tiles)");
 constexpr int LEAF_HALO = 64;   // codes staged on either side of a tile (covers max_codes <= 64)
 
-template <typename KeyT>
+template <typename KeyT, int LEAF_ITEMS>
 __global__ __launch_bounds__(SCAN_THREADS) void k_leaves(const KeyT *__restrict__ unique,
                                                          int max_codes, int32_t *__restrict__ lfc,
                                                          KeyT *__restrict__ leaf_key,
@@ -226,6 +222,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_leaves(const KeyT *__restrict_
                                                          uint32_t *group_status, uint32_t help_spins,
                                                          int late_test)
 {
+    constexpr int LEAF_TILE = SCAN_THREADS * LEAF_ITEMS;
+    static_assert(LEAF_TILE >= 1024, "the look-back rows are sized for tiles of at least 1024 (max_scan_tiles)");
     __shared__ uint32_t s_cnt[LEAF_ITEMS * 4];
     __shared__ uint32_t s_bcast[3];
     __shared__ int s_stuck, s_min;
@@ -558,16 +556,27 @@ static hipError_t build_impl(Sim *s)
         hipLaunchKernelGGL((k_unique<KeyT, IT, HELP>), dim3((n + SCAN_THREADS * IT - 1) / (SCAN_THREADS * IT)), \
                            dim3(SCAN_THREADS), 0, st, sorted, n, (KeyT *) s->unique, s->first_pt, s->counts, \
                            st0, gst0, tk, help, late)
-        const bool big = n >= (1 << 20), by_help = late || n > (1 << 22);
-        if (big) { if (by_help) NB_UNIQUE(2 * SCAN_ITEMS, true); else NB_UNIQUE(2 * SCAN_ITEMS, false); }
+#ifndef NB_UNIQ_BIG_ITEMS
+#define NB_UNIQ_BIG_ITEMS (2 * SCAN_ITEMS)
+#endif
+#ifndef NB_UNIQ_HELP_FROM
+#define NB_UNIQ_HELP_FROM ((1 << 22) + 1)
+#endif
+        const bool big = n >= (1 << 20), by_help = late || n >= NB_UNIQ_HELP_FROM;
+        if (big) { if (by_help) NB_UNIQUE(NB_UNIQ_BIG_ITEMS, true); else NB_UNIQUE(NB_UNIQ_BIG_ITEMS, false); }
         else     { if (by_help) NB_UNIQUE(SCAN_ITEMS, true); else NB_UNIQUE(SCAN_ITEMS, false); }
 #undef NB_UNIQUE
     }
-    const int leaf_grid = (n + LEAF_TILE - 1) / LEAF_TILE;
-    hipLaunchKernelGGL(k_leaves<KeyT>, dim3(leaf_grid), dim3(SCAN_THREADS), 0, st,
-                       (const KeyT *) s->unique, s->p.max_num_codes_per_leaf, s->lfc,
-                       (KeyT *) s->leaf_key, s->counts, s->scan_status + 2 * (size_t) s->max_scan_tiles,
-                       s->scan_status + 3 * (size_t) s->max_scan_tiles, help, late);
+    // tiles of 2048 codes, of 1024 below a million particles (524 k: 17.4 -> 14.5 us; at 2 M the
+    // smaller tile costs 14 us more)
+#define NB_LEAVES(IT)                                                                                  \
+    hipLaunchKernelGGL((k_leaves<KeyT, IT>), dim3((n + SCAN_THREADS * IT - 1) / (SCAN_THREADS * IT)),    \
+                       dim3(SCAN_THREADS), 0, st, (const KeyT *) s->unique, s->p.max_num_codes_per_leaf, \
+                       s->lfc, (KeyT *) s->leaf_key, s->counts,                                          \
+                       s->scan_status + 2 * (size_t) s->max_scan_tiles,                                  \
+                       s->scan_status + 3 * (size_t) s->max_scan_tiles, help, late)
+    if (n < (1 << 20)) NB_LEAVES(4); else NB_LEAVES(8);
+#undef NB_LEAVES
     const int node_grid = std::min((n + 255) / 256, 2048);
     hipLaunchKernelGGL(k_radix<KeyT>, dim3(node_grid), dim3(256), 0, st,
                        (const KeyT *) s->leaf_key, s->counts, s->rt_pd, s->rt_level, s->rt_lb,
