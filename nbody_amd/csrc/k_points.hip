@@ -228,17 +228,26 @@ __global__ __launch_bounds__(256) void k_permute(
     float *__restrict__ vzo)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t s = perm[i];
-    const float px = xi[s], py = yi[s], pz = zi[s], pm = mi[s];
-    xo[i] = px; yo[i] = py; zo[i] = pz; mo[i] = pm;
-    hxo[i] = hxi[s]; hyo[i] = hyi[s]; hzo[i] = hzi[s];
-    ido[i] = idi[s];
-    posm[i] = Float4{px, py, pz, pm};
-    float *pr = posm2 + 8 * (i >> 1) + (i & 1);   // pair record (x0,x1,y0,y1,z0,z1,m0,m1)
-    pr[0] = px; pr[2] = py; pr[4] = pz; pr[6] = pm;
-    if (ALL) {
-        vxo[i] = vxi[s]; vyo[i] = vyi[s]; vzo[i] = vzi[s];
+    const bool in = i < n;
+    float px = 0.f, py = 0.f, pz = 0.f, pm = 0.f;   // (a massless partner pads an odd count)
+    if (in) {
+        const uint32_t s = perm[i];
+        px = xi[s]; py = yi[s]; pz = zi[s]; pm = mi[s];
+        xo[i] = px; yo[i] = py; zo[i] = pz; mo[i] = pm;
+        hxo[i] = hxi[s]; hyo[i] = hyi[s]; hzo[i] = hzi[s];
+        ido[i] = idi[s];
+        posm[i] = Float4{px, py, pz, pm};
+        if (ALL) {
+            vxo[i] = vxi[s]; vyo[i] = vyi[s]; vzo[i] = vzi[s];
+        }
+    }
+    // pair record (x0,x1,y0,y1,z0,z1,m0,m1): the two lanes of a pair trade values, the even one
+    // stores the first half of the record, the odd one the second -- 16 bytes per lane, consecutive
+    const float qx = __shfl_xor(px, 1, 64), qy = __shfl_xor(py, 1, 64);
+    const float qz = __shfl_xor(pz, 1, 64), qm = __shfl_xor(pm, 1, 64);
+    if ((i | 1) - 1 < n) {   // (the odd lane past an odd n completes the last record)
+        const bool odd = i & 1;
+        reinterpret_cast<Float4 *>(posm2)[i] = odd ? Float4{qz, pz, qm, pm} : Float4{px, qx, py, qy};
     }
 }
 
