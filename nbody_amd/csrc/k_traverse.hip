@@ -596,14 +596,15 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
     }
 }
 
-// *out (u64, zeroed by the launcher) += sum over groups of list_len[g] * bodies_in_group(g).
-__global__ __launch_bounds__(256) void k_count_interactions(int n, int group, int g0, int g1,
-                                                            const uint32_t *__restrict__ list_len,
-                                                            unsigned long long *out)
+// *out (u64) = or += sum over groups g0..g1-1 of list_len[g] * bodies_in_group(g).  One workgroup
+// (a few tens of thousands of groups): no partial sums to combine, so nothing to zero first.
+__global__ __launch_bounds__(1024) void k_count_interactions(int n, int group, int g0, int g1,
+                                                             const uint32_t *__restrict__ list_len,
+                                                             unsigned long long *out, int add)
 {
-    __shared__ unsigned long long s[4];
+    __shared__ unsigned long long s[16];
     unsigned long long acc = 0;
-    for (int g = g0 + (int) (blockIdx.x * 256 + threadIdx.x); g < g1; g += (int) gridDim.x * 256) {
+    for (int g = g0 + (int) threadIdx.x; g < g1; g += 1024) {
         const int nb = min(group, n - g * group);
         acc += (unsigned long long) list_len[g] * (unsigned long long) nb;
     }
@@ -612,8 +613,9 @@ __global__ __launch_bounds__(256) void k_count_interactions(int n, int group, in
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned long long t = s[0] + s[1] + s[2] + s[3];
-        if (t) atomicAdd(out, t);
+        unsigned long long t = 0;
+        for (int k = 0; k < 16; ++k) t += s[k];
+        *out = add ? *out + t : t;
     }
 }
 
@@ -802,12 +804,9 @@ hipError_t launch_count_interactions(Sim *s, unsigned long long *out, bool all_g
     const int ngroups = (s->n + s->group - 1) / s->group;
     const int g0 = (all_groups_add || s->trav_g1 < 0) ? 0 : s->trav_g0;
     const int g1 = (all_groups_add || s->trav_g1 < 0) ? ngroups : std::min(s->trav_g1, ngroups);
-    hipError_t e = (all_groups_add || range_add) ? hipSuccess : hipMemsetAsync(out, 0, sizeof(unsigned long long), s->stream);
-    if (e != hipSuccess) return e;
-    if (g1 <= g0) return hipSuccess;
-    const int grid = std::max(1, std::min(64, (g1 - g0 + 255) / 256));
-    hipLaunchKernelGGL(k_count_interactions, dim3(grid), dim3(256), 0, s->stream, s->n, s->group,
-                       g0, g1, s->list_len, out);
+    // (an empty range still has to leave 0 behind when it is not added)
+    hipLaunchKernelGGL(k_count_interactions, dim3(1), dim3(1024), 0, s->stream, s->n, s->group,
+                       g0, std::max(g0, g1), s->list_len, out, (all_groups_add || range_add) ? 1 : 0);
     return hipGetLastError();
 }
 
