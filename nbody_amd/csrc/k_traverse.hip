@@ -604,9 +604,15 @@ __global__ __launch_bounds__(1024) void k_count_interactions(int n, int group, i
 {
     __shared__ unsigned long long s[16];
     unsigned long long acc = 0;
-    for (int g = g0 + (int) threadIdx.x; g < g1; g += 1024) {
-        const int nb = min(group, n - g * group);
-        acc += (unsigned long long) list_len[g] * (unsigned long long) nb;
+    for (int gb = g0 + (int) threadIdx.x; gb < g1; gb += 8 * 1024) {   // eight loads in flight per thread
+        uint32_t len[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) len[k] = list_len[min(gb + k * 1024, g1 - 1)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int g = gb + k * 1024;
+            if (g < g1) acc += (unsigned long long) len[k] * (unsigned long long) min(group, n - g * group);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
