@@ -50,6 +50,10 @@ constexpr int COM_MAX_LEVELS = 24;  // levels of a subtree (a 63-bit key has 21)
 // Nodes of a local subtree whose links a wave keeps in LDS, one packed word each (a subtree with
 // more nodes -- tiny leaves -- reads its links from memory instead).
 constexpr int COM_META_CAP = 384;
+#ifndef NB_COM_GRID
+#define NB_COM_GRID 2048
+#endif
+constexpr int COM_GRID = NB_COM_GRID;   // workgroups of k_com_t (four waves each; they loop over the local roots)
 
 // Every dependent memory round trip of this kernel is paid by a whole wave, so the loads of a
 // step are issued together and waited for once: a subtree's particles go to registers in one

@@ -504,7 +504,7 @@ hipError_t launch64_permute(Sim *s, bool all_fields)
 
 hipError_t launch64_com(Sim *s)
 {
-    const int grid = std::min((2 * s->n + 255) / 256, 2048);
+    const int grid = std::min((2 * s->n + 255) / 256, COM_GRID);
     hipLaunchKernelGGL((k_com_t<double, Double4>), dim3(grid), dim3(256), 0, s->stream, s->counts, s->o_num_children,
                        s->o_first_child, s->o_pb, s->o_pe, s->o_parent, s->d.posm, s->d.wsum,
                        s->d.nodeA, s->com_counter, reinterpret_cast<const uint4 *>(s->depth_key),

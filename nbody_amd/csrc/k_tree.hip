@@ -605,7 +605,7 @@ hipError_t launch_build(Sim *s)
 
 hipError_t launch_com(Sim *s)
 {
-    const int grid = std::min((2 * s->n + 255) / 256, 2048);
+    const int grid = std::min((2 * s->n + 255) / 256, COM_GRID);
     hipLaunchKernelGGL((k_com_t<float, Float4>), dim3(grid), dim3(256), 0, s->stream, s->counts, s->o_num_children,
                        s->o_first_child, s->o_pb, s->o_pe, s->o_parent, s->posm, s->o_wsum,
                        s->nodeA, s->com_counter, reinterpret_cast<const uint4 *>(s->depth_key),
