@@ -177,7 +177,10 @@ def oracle_after_kick_drift(ic, dt, domain, bits, max_codes):
 
 @pytest.mark.parametrize("bits,group", [(10, 64), (21, 64), (21, 32)])
 @pytest.mark.parametrize("kind,n,theta", [("disk", 32768, 0.5), ("clusters", 10000, 0.75),
-                                          ("sphere", 5000, 0.3)])
+                                          ("sphere", 5000, 0.3),
+                                          # odd counts: the last pair record of the sorted
+                                          # position array has one body only
+                                          ("sphere", 4097, 0.5), ("disk", 12345, 0.6)])
 def test_first_update_matches_oracle(bits, group, kind, n, theta):
     """One update(): kick-drift (a = 0), sort, build, traversal, kick."""
     ic = make_ic(kind, n)
