@@ -80,6 +80,17 @@ enum {
                                           float roundings otherwise.  This flag keeps the
                                           general kernel (the reference multiplies by the
                                           mass per pair, include/cuda/physics_common.cuh:62-75). */
+    NBODY_FLAG_NO_COHERENT_SORT = 1u << 6, /* With 63-bit keys a step whose particles have barely
+                                          moved (the reference's time steps: 1e-6 for the sphere and
+                                          the uniform cube, src/renderer.cpp:314-318) sorts only the
+                                          elements whose key left the gap between their neighbours'
+                                          previous keys and merges them into the rest, which is in
+                                          order already -- the same permutation as the full sort,
+                                          chosen from the count of such elements a previous step
+                                          reported.  This flag always runs the digit passes over
+                                          all elements.                                        */
+    NBODY_FLAG_DEBUG_COHERENT_SORT = 1u << 11, /* test aid: take that path whenever the previous
+                                            sort's keys are there, however many elements moved   */
     NBODY_FLAG_DEBUG_SMALL_STACK = 1u << 9, /* test aid: the traversal runs with a node stack of
                                             32 usable entries, so that its overflow handling
                                             (push-backs, depth-first rounds) is exercised;
@@ -231,6 +242,13 @@ int nbody_get_device_ptrs_f64(nbody_t *sim, nbody_dev_view_f64 *out);
 /* The cube the Morton keys of the last build were taken relative to: out[0..2] = lower
  * corner, out[3] = side.  {0, 0, 0, domain_size} without NBODY_FLAG_FIT_KEYS. */
 int nbody_get_key_domain(nbody_t *sim, float *out);
+
+/* How the handle's sorts have gone so far (no counterpart in the reference, which sorts with one
+ * library call, src/cuda/points.cu:73-84): sorts that took the nearly-sorted path (see
+ * NBODY_FLAG_NO_COHERENT_SORT), sorts by digit passes over all elements, and the number of elements
+ * that had left their place in the last sort that counted them (-1: none has).  Waits for the
+ * handle's stream.  Pointers may be NULL. */
+int nbody_get_sort_stats(nbody_t *sim, uint64_t *coherent_sorts, uint64_t *full_sorts, int32_t *last_moved);
 
 /* Sizes of the last built tree: U unique codes, M leaves, n_oct octree nodes. */
 int nbody_get_tree_counts(nbody_t *sim, int32_t *U, int32_t *M, int32_t *n_oct);

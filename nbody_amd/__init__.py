@@ -25,6 +25,8 @@ FLAG_TIMING_STAGES = 1 << 2
 FLAG_FP64 = 1 << 3
 FLAG_FIT_KEYS = 1 << 4
 FLAG_NO_UNIFORM_MASS = 1 << 5
+FLAG_NO_COHERENT_SORT = 1 << 6
+FLAG_DEBUG_COHERENT_SORT = 1 << 11
 FLAG_DEBUG_WALK_ONLY = 1 << 8
 FLAG_DEBUG_SMALL_STACK = 1 << 9
 FLAG_DEBUG_LATE_TILES = 1 << 10
@@ -124,7 +126,7 @@ EXPORTS = [
     "nbody_dd_rebalance", "nbody_dd_step", "nbody_dd_get_stats", "nbody_dd_choose_edges",
     "nbody_dd_refine_edge", "nbody_get_key_domain",
     "nbody_let_export_tree_dev", "nbody_import_trees_dev", "nbody_traverse_forest",
-    "nbody_dd_set_phase_timing", "nbody_dd_get_phases",
+    "nbody_dd_set_phase_timing", "nbody_dd_get_phases", "nbody_get_sort_stats",
 ]
 
 _lib = None
@@ -228,6 +230,8 @@ def load_library() -> C.CDLL:
                                          C.c_uint64, C.c_uint64, C.c_int32]
     lib.nbody_dd_refine_edge.restype = C.c_int32
     lib.nbody_get_key_domain.argtypes = [C.c_void_p, fp]
+    lib.nbody_get_sort_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                         C.POINTER(C.c_int32)]
     _lib = lib
     return lib
 
@@ -452,6 +456,13 @@ class Simulation:
         out = np.empty(4, np.float32)
         self._check(self._lib.nbody_get_key_domain(self._h, _fptr(out)))
         return out
+
+    def sort_stats(self) -> dict:
+        """Sorts that took the nearly-sorted path, sorts by digit passes over everything, and the
+        elements found out of place by the last sort that counted them."""
+        a, b, m = C.c_uint64(), C.c_uint64(), C.c_int32()
+        self._check(self._lib.nbody_get_sort_stats(self._h, C.byref(a), C.byref(b), C.byref(m)))
+        return {"coherent_sorts": a.value, "full_sorts": b.value, "last_moved": m.value}
 
     def tree_counts(self):
         u, m, no = C.c_int32(), C.c_int32(), C.c_int32()

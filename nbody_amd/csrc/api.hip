@@ -59,6 +59,7 @@ void free_all(Sim *s)
     F(s->keybox); F(s->red_scratch); F(s->red_out); F(s->let_mask); F(s->let_seg); F(s->let_frontier);
     F(s->depth_rows); F(s->let_reach); F(s->let_bsum); F(s->imp_roots); F(s->imp_desc);
     if (s->ev_ready) (void) hipEventDestroy(s->ev_ready);
+    if (s->ev_hint) (void) hipEventDestroy(s->ev_hint);
     if (s->red_host) (void) hipHostFree(s->red_host);
     for (int k = 0; k < 3; ++k) { F(s->tw_v[k]); F(s->tw_vh[k]); F(s->tw_a[k]); F(s->ds_a[k]); }
     State64 &d = s->d;
@@ -70,6 +71,8 @@ void free_all(Sim *s)
     F(d.tw_pot); F(d.ds_pot);
     for (int k = 0; k < 3; ++k) { F(d.tw_v[k]); F(d.tw_vh[k]); F(d.tw_a[k]); F(d.ds_a[k]); }
     if (s->counts_host) (void) hipHostFree(s->counts_host);
+    if (s->coh_host) (void) hipHostFree(s->coh_host);
+    F(s->coh_ctl);
     for (int r = 0; r < TIMING_RING; ++r)
         for (int k = 0; k < EV_COUNT; ++k)
             if (s->ev[r][k]) (void) hipEventDestroy(s->ev[r][k]);
@@ -132,6 +135,13 @@ int alloc_all(Sim *s)
     s->scan_status = zw + 16;
     s->dhist = s->scan_status + 4 * (size_t) s->max_scan_tiles;
     s->rank_status = s->dhist + 256;
+    if (s->key_bytes == 8) {
+        NB_HIP(s, dalloc(&s->coh_ctl, 4));
+        NB_HIP(s, hipMemsetAsync(s->coh_ctl, 0, 16, s->stream));
+        NB_HIP(s, hipHostMalloc((void **) &s->coh_host, 2 * sizeof(int32_t)));
+        s->coh_host[0] = -1; s->coh_host[1] = 0;
+        NB_HIP(s, hipEventCreateWithFlags(&s->ev_hint, hipEventDisableTiming));
+    }
     NB_HIP(s, dalloc(&s->depth_rows, (size_t) 2048 * 32));
     NB_HIP(s, dalloc(&s->com_counter, 2 * n));
     NB_HIP(s, hipMemsetAsync(s->com_counter, 0, 2 * n * 4, s->stream));
@@ -1000,6 +1010,16 @@ int nbody_get_key_domain(nbody_t *h, float *out)
     if (!s->keybox) return NBODY_OK;
     NB_HIP(s, hipMemcpyAsync(out, s->keybox, 4 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
     NB_HIP(s, hipStreamSynchronize(s->stream));
+    return NBODY_OK;
+}
+
+int nbody_get_sort_stats(nbody_t *h, uint64_t *coherent_sorts, uint64_t *full_sorts, int32_t *last_moved)
+{
+    NB_ENTER(h);
+    NB_HIP(s, hipStreamSynchronize(s->stream));
+    if (coherent_sorts) *coherent_sorts = s->coh_sorts;
+    if (full_sorts) *full_sorts = s->full_sorts;
+    if (last_moved) *last_moved = s->coh_host ? s->coh_host[0] : -1;
     return NBODY_OK;
 }
 

@@ -37,10 +37,12 @@ namespace nb {
 
 // digits P0 .. NPASS-1 (ghist keeps one row of 256 per digit, rows below P0 stay zero)
 template <typename KeyT, int NPASS, int P0>
-__global__ __launch_bounds__(NB_HIST_THREADS) void k_sort_hist(const KeyT *__restrict__ keys, int n,
-                                                               uint32_t *__restrict__ ghist)
+__global__ __launch_bounds__(NB_HIST_THREADS) void k_sort_hist(const KeyT *__restrict__ keys, int n_host,
+                                                               uint32_t *__restrict__ ghist,
+                                                               const int32_t *n_dev)
 {
     constexpr int HT = NB_HIST_THREADS;
+    const int n = n_dev ? *n_dev : n_host;   // (device-side count: the moved elements of a coherent sort)
     __shared__ uint32_t h[NPASS * 256];
     for (int j = threadIdx.x + P0 * 256; j < NPASS * 256; j += HT) h[j] = 0;
     __syncthreads();
@@ -109,11 +111,9 @@ constexpr int TIE_SHORT = 16;   // longest run one thread orders (in registers);
 constexpr int TIE_REG = TIE_SHORT;
 
 template <typename KeyT>
-__global__ __launch_bounds__(256) void k_tiefix(KeyT *keys, uint32_t *vals, int n, int low_bits,
-                                                uint32_t *__restrict__ long_runs,
-                                                uint32_t *long_count)
+__device__ __forceinline__ void tiefix_at(KeyT *keys, uint32_t *vals, int n, int low_bits,
+                                          uint32_t *__restrict__ long_runs, uint32_t *long_count, int i)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
     const bool in = i < n;
     const int ci = in ? i : n - 1;
     // a run starts where a key agrees (in its upper bits) with its successor and not with its
@@ -176,17 +176,29 @@ __global__ __launch_bounds__(256) void k_tiefix(KeyT *keys, uint32_t *vals, int 
     }
 }
 
+// (grid-stride: the launch may have fewer workgroups than n / 256, e.g. when n is a device-side count)
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_tiefix(KeyT *keys, uint32_t *vals, int n_host, int low_bits,
+                                                uint32_t *__restrict__ long_runs,
+                                                uint32_t *long_count, const int32_t *n_dev)
+{
+    const int n = n_dev ? *n_dev : n_host;
+    for (int b = (int) blockIdx.x; b * 256 < n; b += (int) gridDim.x)
+        tiefix_at<KeyT>(keys, vals, n, low_bits, long_runs, long_count, b * 256 + (int) threadIdx.x);
+}
+
 // One wave per long run: low_bits / 8 stable 8-bit LSD passes over the run, between the run's
 // place in the sorted buffers (k0, v0) and the same place in the other buffer pair (k1, v1),
 // whose contents are dead after the digit passes.  64 elements at a time, in order: lanes with
 // the same digit rank themselves by ballot matching, the digit's running offset lives in LDS.
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_tiefix_long(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1,
-                                                     int n, int low_bits,
+                                                     int n_host, int low_bits,
                                                      const uint32_t *__restrict__ long_runs,
-                                                     const uint32_t *long_count)
+                                                     const uint32_t *long_count, const int32_t *n_dev)
 {
     __shared__ uint32_t s_base[4][256];
+    const int n = n_dev ? *n_dev : n_host;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t *base = s_base[w];
     const int nruns = (int) __hip_atomic_load(long_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -397,8 +409,17 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_pass(
             vout[gpos] = v;
             if (inv_out) inv_out[v] = gpos;
         }
-        if (!HELP || tile == own) return;
-        tile = own;   // a helped tile is done: now this workgroup's own, from the start
+        if (!HELP) return;
+        // a helped tile is done: now this workgroup's own, from the start; its own is done: on to
+        // the next one it owns, when the launch has fewer workgroups than tiles (a workgroup takes
+        // its tiles in ascending order, so whoever a tile waits for is at work on it or on a lower
+        // one, which needs nothing from above)
+        if (tile == own) {
+            own += (int) gridDim.x;
+            if (own >= ntiles) return;
+            rounds = 0;
+        }
+        tile = own;
         __syncthreads();   // (the write-out has read s_keys / s_goff)
     }
 }
@@ -415,6 +436,221 @@ void launch_rank_pass(const uint32_t *keys, uint32_t *keys_out, uint32_t *vals_o
                        keys, (const uint32_t *) nullptr, keys_out, vals_out, inv_out, n_dev, 0, 0,
                        hist, status, status + (size_t) grid * 256, (uint32_t *) nullptr,
                        late_test ? LB_TEST_SPINS : LB_HELP_SPINS, late_test ? 1 : 0, err);
+}
+
+
+// ---------------------------------------------------------------------------
+// Sort of keys that are NEARLY in order already.  A step starts from the particle order the
+// previous step's sort left behind, and with the reference's time steps (1e-6 for the sphere,
+// src/renderer.cpp:314-318) a particle's new key rarely leaves the gap between its neighbours'
+// old keys.  With O the previous step's sorted keys (O[i] = old key of the particle now at index
+// i) and m_i = O[i] + (O[i+1] - O[i]) / 2, element i STAYS iff its new key lies in
+// (m_{i-1}, m_i]: these intervals are disjoint and ascending, so the staying elements are in
+// strictly ascending key order whatever the others do.  The others (MOVED: a key that crossed
+// a cell boundary coarser than the distance to the neighbour) are compacted in index order,
+// sorted by the ordinary digit passes with a device-side count, and merged back:
+//   staying i : position = (staying elements before i) + (moved elements below (key_i, i))
+//   moved j-th: position = j + (staying elements below its (key, index))
+// which is the stable sort of everything, the same permutation the digit passes over all n
+// elements produce.  Nothing here depends on how many elements moved; only the time does, and
+// the host picks this path from the count a previous step reported (sort_impl).
+// ---------------------------------------------------------------------------
+constexpr int COH_ITEMS = 8;
+constexpr int COH_TILE = 256 * COH_ITEMS;        // 2048 elements = 32 ballot words per tile
+constexpr int COH_WORDS = COH_TILE / 64;
+constexpr int COH_MERGE_EXTRA = 1024;
+constexpr int COH_SORT_GRID = 256;                // workgroups of a digit pass over the moved elements (they loop)
+constexpr int COH_MAX_SHARE = 64;                // this path when at most n / 64 elements moved last time (break-even: 1 in 52 at 2 M keys)            // workgroups of k_coh_merge that place the moved elements
+
+// k_coh_scan: ctl[0] = moved count; host2[0] = moved count, host2[1] = n (pinned host memory, read
+// by the host without synchronisation: a hint, never an input).
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_coh_flags(const KeyT *__restrict__ knew, const KeyT *__restrict__ kold,
+                                                   int n, unsigned long long *__restrict__ bits,
+                                                   uint32_t *__restrict__ tile_cnt)
+{
+    __shared__ uint32_t s_red[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tile = blockIdx.x;
+    const int base = tile * COH_TILE;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int j = 0; j < COH_ITEMS; ++j) {
+        const int i = base + j * 256 + tid;
+        bool stay = false;
+        if (i < n) {
+            const KeyT k = knew[i], oc = kold[i];
+            const KeyT op = kold[max(i - 1, 0)], on = kold[min(i + 1, n - 1)];
+            const bool above = i == 0 || k > op + ((oc - op) >> 1);
+            const bool below = i == n - 1 || k <= oc + ((on - oc) >> 1);
+            stay = above && below;
+        }
+        const unsigned long long b = __ballot(stay);
+        if (lane == 0 && base + j * 256 + w * 64 < n) bits[(base >> 6) + j * 4 + w] = b;
+        cnt += (uint32_t) __popcll(b);
+    }
+    if (lane == 0) s_red[w] = cnt;   // (cnt is wave-uniform)
+    __syncthreads();
+    if (tid == 0) tile_cnt[tile] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+// Exclusive prefix of the tiles' staying counts, the moved count (one workgroup).
+__global__ __launch_bounds__(1024) void k_coh_scan(int n, int ntiles, const uint32_t *__restrict__ tile_cnt,
+                                                   uint32_t *__restrict__ tile_sbase, int32_t *ctl, int32_t *host2)
+{
+    __shared__ uint32_t s_scan[17];
+    const int tid = threadIdx.x;
+    uint32_t carry = 0;
+    for (int t0 = 0; t0 < ntiles; t0 += 1024) {
+        const int t = t0 + tid;
+        const uint32_t c = t < ntiles ? tile_cnt[t] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan_u32<16>(c, s_scan, &tot);
+        if (t < ntiles) tile_sbase[t] = carry + ex;
+        carry += tot;
+    }
+    if (tid == 0) {
+        const int moved = n - (int) carry;
+        ctl[0] = moved;
+        __hip_atomic_store(&host2[1], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host2[0], moved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// Staying elements before element `at` of tile `tile` (words = the tile's ballots in LDS or global).
+__device__ __forceinline__ uint32_t coh_below(unsigned long long word, int lane)
+{
+    return (uint32_t) __popcll(word & ((1ull << lane) - 1ull));
+}
+
+// The moved elements, in index order, into (mk, mv).
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_coh_collect(const KeyT *__restrict__ knew, int n,
+                                                     const unsigned long long *__restrict__ bits,
+                                                     const uint32_t *__restrict__ tile_sbase,
+                                                     KeyT *__restrict__ mk, uint32_t *__restrict__ mv)
+{
+    __shared__ unsigned long long s_w[COH_WORDS];
+    __shared__ uint32_t s_pre[COH_WORDS];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tile = blockIdx.x, base = tile * COH_TILE;
+    const int tile_n = min(COH_TILE, n - base);
+    if (tid < COH_WORDS) s_w[tid] = tid * 64 < tile_n ? bits[(base >> 6) + tid] : 0ull;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t a = 0;
+        for (int q = 0; q < COH_WORDS; ++q) { s_pre[q] = a; a += (uint32_t) __popcll(s_w[q]); }
+    }
+    __syncthreads();
+    const uint32_t sb = tile_sbase[tile];
+#pragma unroll
+    for (int j = 0; j < COH_ITEMS; ++j) {
+        const int i = base + j * 256 + tid;
+        const unsigned long long word = s_w[j * 4 + w];
+        if (i < n && !((word >> lane) & 1ull)) {
+            const uint32_t srank = sb + s_pre[j * 4 + w] + coh_below(word, lane);
+            const uint32_t m = (uint32_t) i - srank;
+            mk[m] = knew[i];
+            mv[m] = (uint32_t) i;
+        }
+    }
+}
+
+// Final places.  Workgroups [0, ntiles): the staying elements of one tile; the other
+// COH_MERGE_EXTRA workgroups: the moved elements, one wave each at a time.
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_coh_merge(const KeyT *__restrict__ knew, const KeyT *__restrict__ kold,
+                                                   int n, int ntiles,
+                                                   const unsigned long long *__restrict__ bits,
+                                                   const uint32_t *__restrict__ tile_sbase,
+                                                   const int32_t *__restrict__ ctl,
+                                                   const KeyT *__restrict__ mk, const uint32_t *__restrict__ mv,
+                                                   KeyT *__restrict__ kout, uint32_t *__restrict__ vout)
+{
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int K = ctl[0];
+    if ((int) blockIdx.x >= ntiles) {
+        // ---- moved elements: j-th of the sorted ones -> j + staying elements below it ----
+        const int wave0 = ((int) blockIdx.x - ntiles) * 4 + w, nwaves = ((int) gridDim.x - ntiles) * 4;
+        for (int j = wave0; j < K; j += nwaves) {
+            const KeyT km = mk[j];
+            const uint32_t im = mv[j];
+            // p = first index whose upper interval bound m_p is >= km (m_{n-1} = infinity): 64 probes a round
+            int lo = 0, hi = n - 1;
+            while (lo < hi) {
+                const int chunk = (hi - lo) / 64 + 1;   // 64 * chunk > hi - lo: the last lane probes hi
+                const int q = min(lo + (lane + 1) * chunk - 1, hi);
+                bool ok = true;
+                if (q < n - 1) {
+                    const KeyT a = kold[q], b = kold[q + 1];
+                    ok = a + ((b - a) >> 1) >= km;
+                }
+                const unsigned long long okm = __ballot(ok);   // not empty: the last lane probes hi
+                const int f = (int) __builtin_ctzll(okm);
+                const int qf = min(lo + (f + 1) * chunk - 1, hi);
+                if (f > 0) lo = min(lo + f * chunk - 1, hi) + 1;
+                hi = qf;
+            }
+            const int p = lo;
+            const int t = p / COH_TILE, wi = (p % COH_TILE) >> 6;
+            const unsigned long long word = lane <= wi ? bits[(size_t) t * COH_WORDS + lane] : 0ull;
+            uint32_t c = lane < wi ? (uint32_t) __popcll(word) : (lane == wi ? coh_below(word, p & 63) : 0u);
+            c = wave_sum_u32(c) + tile_sbase[t];
+            const unsigned long long wp = __shfl(word, wi, 64);
+            if ((wp >> (p & 63)) & 1ull) {
+                const KeyT kp = knew[p];
+                if (kp < km || (kp == km && (uint32_t) p < im)) ++c;
+            }
+            if (lane == 0) {
+                kout[(uint32_t) j + c] = km;
+                vout[(uint32_t) j + c] = im;
+            }
+        }
+        return;
+    }
+    // ---- staying elements: staying rank + moved elements below (key, index) ----
+    __shared__ unsigned long long s_w[COH_WORDS];
+    __shared__ uint32_t s_pre[COH_WORDS];
+    __shared__ int s_m[2];
+    const int tile = blockIdx.x, base = tile * COH_TILE;
+    const int tile_n = min(COH_TILE, n - base);
+    if (tid < COH_WORDS) s_w[tid] = tid * 64 < tile_n ? bits[(base >> 6) + tid] : 0ull;
+    if (tid == 64 || tid == 128) {
+        // the moved keys that can fall among this tile's staying keys lie in [O[base-1], O[end]]
+        int lo = 0, hi = K;
+        if (tid == 64) {
+            if (base > 0) { const KeyT b = kold[base - 1]; while (lo < hi) { const int mid = (lo + hi) >> 1; if (mk[mid] < b) lo = mid + 1; else hi = mid; } }
+            s_m[0] = base > 0 ? lo : 0;
+        } else {
+            if (base + COH_TILE < n) { const KeyT b = kold[base + COH_TILE]; while (lo < hi) { const int mid = (lo + hi) >> 1; if (mk[mid] <= b) lo = mid + 1; else hi = mid; } }
+            s_m[1] = base + COH_TILE < n ? lo : K;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t a = 0;
+        for (int q = 0; q < COH_WORDS; ++q) { s_pre[q] = a; a += (uint32_t) __popcll(s_w[q]); }
+    }
+    __syncthreads();
+    const uint32_t sb = tile_sbase[tile];
+    const int mlo = s_m[0], mhi = s_m[1];
+#pragma unroll
+    for (int j = 0; j < COH_ITEMS; ++j) {
+        const int i = base + j * 256 + tid;
+        const unsigned long long word = s_w[j * 4 + w];
+        if (i < n && ((word >> lane) & 1ull)) {
+            const KeyT k = knew[i];
+            int lo = mlo, hi = mhi;   // first moved element of [mlo, mhi) not below (k, i)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const KeyT km = mk[mid];
+                if (km < k || (km == k && mv[mid] < (uint32_t) i)) lo = mid + 1; else hi = mid;
+            }
+            const uint32_t pos = sb + s_pre[j * 4 + w] + coh_below(word, lane) + (uint32_t) lo;
+            kout[pos] = k;
+            vout[pos] = (uint32_t) i;
+        }
+    }
 }
 
 constexpr int SORT_TICKET_TILES = 256;
@@ -443,11 +679,87 @@ static hipError_t sort_impl(Sim *s)
     uint32_t *tickets = s->ghist + 8 * 256;
     uint32_t *status = tickets + 16;
     const int hgrid = std::min(std::max((n + NB_HIST_THREADS * NB_HIST_KEYS - 1) / (NB_HIST_THREADS * NB_HIST_KEYS), 1), NB_HIST_GRID);
-    hipLaunchKernelGGL((k_sort_hist<KeyT, NPASS, P0>), dim3(hgrid), dim3(NB_HIST_THREADS), 0, s->stream,
-                       (const KeyT *) s->keys[0], n, s->ghist);
     // (test aid: late workgroups and an early give-up exercise the helping path of the look-back)
     const int late = (s->p.flags & NBODY_FLAG_DEBUG_LATE_TILES) ? 1 : 0;
     const uint32_t help = late ? LB_TEST_SPINS : LB_HELP_SPINS;
+
+    // Nearly sorted already?  (see k_coh_flags)  The previous sort's keys must be those of the
+    // current particle order: same count, result in keys[1], new keys in keys[0].
+    bool coherent = false, probe = false;
+    if constexpr (sizeof(KeyT) == 8 && P0 > 0) {
+        if (s->coh_ctl && s->old_keys_n == n && s->sorted_buf == 1 && n >= 4 * COH_TILE &&
+            !(s->p.flags & NBODY_FLAG_NO_COHERENT_SORT)) {
+            if (s->p.flags & NBODY_FLAG_DEBUG_COHERENT_SORT) {
+                coherent = true;
+            } else {
+                // The moved count the PREVIOUS sort reported, if that sort has finished by now (a
+                // caller that queues many steps without waiting is ahead of the device, and a count
+                // from many steps ago says nothing: a system starting from rest has none moved in
+                // its first step and a quarter a hundred steps later).  Decides which way is
+                // faster, never what comes out.
+                const bool fresh = s->hint_call + 1 == s->sort_calls && s->ev_hint &&
+                                   hipEventQuery(s->ev_hint) == hipSuccess;
+                const int hint = s->coh_host[0], hint_n = s->coh_host[1];
+                if (fresh && hint_n == n && hint >= 0 && (long long) hint * COH_MAX_SHARE <= (long long) n) coherent = true;
+                else probe = (s->sort_calls & 7u) == 1u;   // look again now and then
+            }
+        }
+    }
+    ++s->sort_calls;
+    const int ctiles = (n + COH_TILE - 1) / COH_TILE;
+    unsigned long long *bits = (unsigned long long *) s->rt_le;      // n / 8 bytes of the n * 4
+    uint32_t *tile_cnt = (uint32_t *) s->rt_left, *tile_sbase = tile_cnt + ctiles;
+    if constexpr (sizeof(KeyT) == 8 && P0 > 0) {
+    if (coherent || probe) {
+        hipLaunchKernelGGL(k_coh_flags<KeyT>, dim3(ctiles), dim3(256), 0, s->stream, (const KeyT *) s->keys[0],
+                           (const KeyT *) s->keys[1], n, bits, tile_cnt);
+        hipLaunchKernelGGL(k_coh_scan, dim3(1), dim3(1024), 0, s->stream, n, ctiles, (const uint32_t *) tile_cnt,
+                           tile_sbase, s->coh_ctl, s->coh_host);
+        if (s->ev_hint && hipEventRecord(s->ev_hint, s->stream) == hipSuccess) s->hint_call = s->sort_calls - 1;
+    }
+    if (coherent) {
+        // moved elements: (unique, vals[0]) <-> (leaf_key, vals[1]); NPASS - P0 = 5 passes end in the second pair
+        KeyT *kb[2] = {(KeyT *) s->unique, (KeyT *) s->leaf_key};
+        uint32_t *vb[2] = {s->vals[0], s->vals[1]};
+        const int32_t *n_moved = s->coh_ctl;
+        hipLaunchKernelGGL(k_coh_collect<KeyT>, dim3(ctiles), dim3(256), 0, s->stream, (const KeyT *) s->keys[0], n,
+                           (const unsigned long long *) bits, (const uint32_t *) tile_sbase, kb[0], vb[0]);
+        hipLaunchKernelGGL((k_sort_hist<KeyT, NPASS, P0>), dim3(hgrid), dim3(NB_HIST_THREADS), 0, s->stream,
+                           (const KeyT *) kb[0], 0, s->ghist, n_moved);
+        int in = 0;
+        for (int p = P0; p < NPASS; ++p) {
+            uint32_t *st = status + (size_t) (p - P0) * rows * 256;
+            hipLaunchKernelGGL((k_sort_pass<KeyT, SORT_ITEMS, false, true>), dim3(std::min(tiles, COH_SORT_GRID)), dim3(SORT_THREADS), 0,
+                               s->stream, (const KeyT *) kb[in], (const uint32_t *) vb[in], kb[in ^ 1], vb[in ^ 1],
+                               (uint32_t *) nullptr, n_moved, 0, 8 * p, s->ghist + p * 256, st,
+                               st + (size_t) tiles * 256, tickets + p, help, late, &s->counts->err);
+            in ^= 1;
+        }
+        uint32_t *long_runs = (uint32_t *) s->rt_lb;
+        uint32_t *long_count = tickets + 8;
+        hipLaunchKernelGGL(k_tiefix<KeyT>, dim3(std::min((n + 255) / 256, 1024)), dim3(256), 0, s->stream, kb[in], vb[in], 0,
+                           8 * P0, long_runs, long_count, n_moved);
+        hipLaunchKernelGGL(k_tiefix_long<KeyT>, dim3(std::min((n / TIE_SHORT + 3) / 4 + 1, 256)), dim3(256), 0,
+                           s->stream, kb[in], vb[in], kb[in ^ 1], vb[in ^ 1], 0, 8 * P0,
+                           (const uint32_t *) long_runs, (const uint32_t *) long_count, n_moved);
+        // merged result -> the first pair, which then becomes keys[1] / vals[1]; the old sorted
+        // keys' buffer serves as the unique-key buffer from here on
+        hipLaunchKernelGGL(k_coh_merge<KeyT>, dim3(ctiles + COH_MERGE_EXTRA), dim3(256), 0, s->stream,
+                           (const KeyT *) s->keys[0], (const KeyT *) s->keys[1], n, ctiles,
+                           (const unsigned long long *) bits, (const uint32_t *) tile_sbase, n_moved,
+                           (const KeyT *) kb[in], (const uint32_t *) vb[in], kb[in ^ 1], vb[in ^ 1]);
+        static_assert(((NPASS - P0) & 1) == 1, "an odd number of passes ends in the second buffer pair");
+        std::swap(s->keys[1], s->unique);
+        std::swap(s->vals[0], s->vals[1]);
+        s->sorted_buf = 1;
+        s->old_keys_n = n;
+        ++s->coh_sorts;
+        return hipGetLastError();
+    }
+    }
+
+    hipLaunchKernelGGL((k_sort_hist<KeyT, NPASS, P0>), dim3(hgrid), dim3(NB_HIST_THREADS), 0, s->stream,
+                       (const KeyT *) s->keys[0], n, s->ghist, (const int32_t *) nullptr);
     // numbering by ticket up to a few hundred tiles, by blockIdx (with helping) beyond: a pass of
     // 128 tiles 14.4 against 15.6 us, of 512 tiles 25.5 against 22.4 us; the test mode always
     // takes the second
@@ -470,6 +782,8 @@ static hipError_t sort_impl(Sim *s)
         in ^= 1;
     }
     s->sorted_buf = in;
+    s->old_keys_n = n;
+    ++s->full_sorts;
     if (P0 > 0) {
         // runs of equal upper bits: heads of the long ones are listed in the (not yet used)
         // unique-key buffer, counted in a spare ticket word of the block zeroed above
@@ -477,10 +791,10 @@ static hipError_t sort_impl(Sim *s)
         uint32_t *long_count = tickets + 8;
         KeyT *k0 = (KeyT *) s->keys[in], *k1 = (KeyT *) s->keys[in ^ 1];
         hipLaunchKernelGGL(k_tiefix<KeyT>, dim3((n + 255) / 256), dim3(256), 0, s->stream, k0,
-                           s->vals[in], n, 8 * P0, long_runs, long_count);
+                           s->vals[in], n, 8 * P0, long_runs, long_count, (const int32_t *) nullptr);
         hipLaunchKernelGGL(k_tiefix_long<KeyT>, dim3(std::min((n / TIE_SHORT + 3) / 4 + 1, 256)), dim3(256), 0,
                            s->stream, k0, s->vals[in], k1, s->vals[in ^ 1], n, 8 * P0,
-                           (const uint32_t *) long_runs, (const uint32_t *) long_count);
+                           (const uint32_t *) long_runs, (const uint32_t *) long_count, (const int32_t *) nullptr);
     }
     return hipGetLastError();
 }

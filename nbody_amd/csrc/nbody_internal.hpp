@@ -147,6 +147,16 @@ struct Sim {
     uint32_t *sort_status = nullptr;  // [passes][sort_status_rows(tiles)][256] look-back words + tickets
     size_t sort_status_bytes = 0;
     int sort_tiles = 0;
+    // sort of nearly sorted keys (k_sort.hip, k_coh_*): device control words, the moved count the
+    // last such pass reported (pinned: {moved, n}), the element count of the keys the last sort left
+    // in keys[sorted_buf], how many sorts went which way
+    int32_t *coh_ctl = nullptr;
+    int32_t *coh_host = nullptr;
+    int old_keys_n = -1;
+    uint32_t sort_calls = 0;
+    hipEvent_t ev_hint = nullptr;   // after the kernel that reports the moved count
+    uint32_t hint_call = ~0u - 1;   // the sort call (0-based) that recorded it
+    uint64_t coh_sorts = 0, full_sorts = 0;
 
     // scratch zeroed once per build (tickets, look-back words, counters, histograms)
     uint8_t *zero_block = nullptr;   // build part, then the sort's part (ghist points into it)

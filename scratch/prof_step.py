@@ -8,6 +8,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 21
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 group = int(sys.argv[4]) if len(sys.argv) > 4 else 64
 flags = nb.FLAG_FP64 if len(sys.argv) > 5 and sys.argv[5] == "f64" else 0
+flags |= int(os.environ.get("NBODY_EXTRA_FLAGS", "0"))
 kind = sys.argv[6] if len(sys.argv) > 6 else "sphere"
 kw = {"sphere": dict(theta=0.6, dt=1e-6, softening_factor=0.1),
       "plummer": dict(theta=0.6, dt=1e-6, softening_factor=1e-3),
