@@ -589,6 +589,36 @@ def main():
                 "build_ms": round((t8["ms_integrate"] + t8["ms_sort"] + t8["ms_build"] + t8["ms_com"]) / 50, 4),
                 "interactions_per_step": round(t8["interactions"] / 50),
                 "traversal_tflops": round(FLOP_PER_INTERACTION * t8["interactions"] / (t8["ms_traverse"] * 1e-3) / 1e12, 2)}
+    slow = None
+    if world == 1 and not args.no_alt_bits and not args.walk_only and args.morton_bits == 21:
+        # A system whose particles move less than the distance to their neighbours per step (cold
+        # Plummer sphere, total mass 1, the reference's dt = 1e-6), stepped the way a viewer steps
+        # it -- one update, then a wait -- so that every sort knows how the previous one went:
+        # the sort of nearly sorted keys against the digit passes over all elements.
+        ns = 2_097_152
+        ics = nb.sample_ic(nb.IC_PLUMMER, ns, 42, p0=0.1, p1=1.0)
+        res = {}
+        for name, fl in (("digit_passes_over_all", nb.FLAG_NO_COHERENT_SORT), ("nearly_sorted_path", 0)):
+            ps_ = nb.Params(num_points=ns, max_num_codes_per_leaf=32, traversal_group_size=group, theta=THETA,
+                            dt=1e-6, gravity=1.0, softening_factor=1e-3, domain_size=5.0, morton_bits=21,
+                            device_id=local_rank, flags=nb.FLAG_TIMING | nb.FLAG_TIMING_STAGES | fl)
+            with nb.Simulation(ps_) as s9:
+                s9.set_state(ics["x"], ics["y"], ics["z"], ics["m"], ics["vx"], ics["vy"], ics["vz"])
+                for _ in range(4):
+                    s9.update(); s9.sync()
+                s9.get_timings()
+                for _ in range(20):
+                    s9.update(); s9.sync()
+                t9 = s9.get_timings()
+                st9 = s9.sort_stats()
+            res[name] = {"sort_and_permute_ms": round(t9["ms_sort"] / 20, 4),
+                         "build_ms": round((t9["ms_integrate"] + t9["ms_sort"] + t9["ms_build"] + t9["ms_com"]) / 20, 4),
+                         "sorts": {"nearly_sorted": st9["coherent_sorts"], "all_elements": st9["full_sorts"]},
+                         "moved_elements_last_step": st9["last_moved"]}
+        slow = {"workload": "2,097,152-particle Plummer sphere at rest (total mass 1), theta=%.2f, eps=1e-3, dt=1e-6, "
+                            "63-bit keys, one update then a wait per step" % THETA, **res,
+                "note": "the timed region of this line queues its steps without waiting, so its sorts cannot "
+                        "know how the previous one went and run the digit passes over all elements"}
     direct = None
     if world == 1 and not args.no_direct_sum and not args.walk_only:
         direct = direct_sum_block(args.no_cpu_baseline)
@@ -729,6 +759,8 @@ def main():
             out["fitted_30bit_keys"] = fit
         if disk is not None:
             out["disk_524k"] = disk
+        if slow is not None:
+            out["slow_system_sort"] = slow
         if direct is not None:
             out["direct_sum"] = direct
         if g32 is not None:

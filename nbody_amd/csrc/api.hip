@@ -344,6 +344,9 @@ int fetch_counts(Sim *s)
 // update_points + update_octree (src/cuda/simulation.cu:75-102) after the keys are encoded.
 int build_after_encode(Sim *s, bool permute_all)
 {
+    // a particle set that has just arrived (upload, spawn, snapshot, migration) is in no order
+    // that the previous sort's keys describe
+    if (permute_all) s->old_keys_n = -1;
     NB_HIP(s, launch_sort(s));
     NB_HIP(s, s->fp64 ? launch64_permute(s, permute_all) : launch_permute(s, permute_all));
     return NBODY_OK;
@@ -1339,6 +1342,7 @@ int nbody_set_sources_dev(nbody_t *h, const float *posm_dev, int32_t count)
     NB_HIP(s, hipMemsetAsync(s->counts, 0, sizeof(Counts), s->stream));
     NB_HIP(s, launch_unpack_sources(s, reinterpret_cast<const Float4 *>(posm_dev), count));
     NB_HIP(s, launch_morton_only(s));
+    s->old_keys_n = -1;   // (records in the sender's order)
     int rc = build_after_encode(s, false);
     if (rc) return rc;
     NB_HIP(s, launch_build(s));
