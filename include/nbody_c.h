@@ -89,8 +89,13 @@ enum {
                                           chosen from the count of such elements a previous step
                                           reported.  This flag always runs the digit passes over
                                           all elements.                                        */
-    NBODY_FLAG_DEBUG_COHERENT_SORT = 1u << 11, /* test aid: take that path whenever the previous
-                                            sort's keys are there, however many elements moved   */
+    NBODY_FLAG_ALWAYS_COHERENT_SORT = 1u << 11, /* take that path on every sort whose predecessor's
+                                            keys are there, however many elements moved and whether or
+                                            not the previous sort has finished: for a caller that
+                                            queues many steps of a slowly moving system without
+                                            waiting (correct for any input; slower than the digit
+                                            passes over everything once more than about 1 element in
+                                            50 moves per step), and for the tests                  */
     NBODY_FLAG_DEBUG_SMALL_STACK = 1u << 9, /* test aid: the traversal runs with a node stack of
                                             32 usable entries, so that its overflow handling
                                             (push-backs, depth-first rounds) is exercised;

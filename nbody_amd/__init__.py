@@ -26,7 +26,7 @@ FLAG_FP64 = 1 << 3
 FLAG_FIT_KEYS = 1 << 4
 FLAG_NO_UNIFORM_MASS = 1 << 5
 FLAG_NO_COHERENT_SORT = 1 << 6
-FLAG_DEBUG_COHERENT_SORT = 1 << 11
+FLAG_ALWAYS_COHERENT_SORT = 1 << 11
 FLAG_DEBUG_WALK_ONLY = 1 << 8
 FLAG_DEBUG_SMALL_STACK = 1 << 9
 FLAG_DEBUG_LATE_TILES = 1 << 10

@@ -687,9 +687,13 @@ static hipError_t sort_impl(Sim *s)
     // current particle order: same count, result in keys[1], new keys in keys[0].
     bool coherent = false, probe = false;
     if constexpr (sizeof(KeyT) == 8 && P0 > 0) {
+        // (not while the stream is being captured into a graph: this path trades buffers between
+        // calls and asks an event how far the device is, neither of which a replay repeats)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s->stream, &cap) != hipSuccess) cap = hipStreamCaptureStatusActive;
         if (s->coh_ctl && s->old_keys_n == n && s->sorted_buf == 1 && n >= 4 * COH_TILE &&
-            !(s->p.flags & NBODY_FLAG_NO_COHERENT_SORT)) {
-            if (s->p.flags & NBODY_FLAG_DEBUG_COHERENT_SORT) {
+            cap == hipStreamCaptureStatusNone && !(s->p.flags & NBODY_FLAG_NO_COHERENT_SORT)) {
+            if (s->p.flags & NBODY_FLAG_ALWAYS_COHERENT_SORT) {
                 coherent = true;
             } else {
                 // The moved count the PREVIOUS sort reported, if that sort has finished by now (a

@@ -39,7 +39,7 @@ def run(flags, timed=int(os.environ.get("COH_TIMED", "40"))):
 
 
 pa, sa, ta, tma, sta = run(nb.FLAG_NO_COHERENT_SORT)
-for name, fl in (("forced", nb.FLAG_DEBUG_COHERENT_SORT), ("auto", 0)):
+for name, fl in (("forced", nb.FLAG_ALWAYS_COHERENT_SORT), ("auto", 0)):
     pb, sb, tb, tmb, stb = run(fl)
     same_perm = all((a[0] == b[0]).all() and (a[1] == b[1]).all() for a, b in zip(pa, pb))
     same_state = all((sa[k].view(np.uint32) == sb[k].view(np.uint32)).all() for k in ("x", "vx", "ax", "az"))

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nbody_amd as nb
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 21
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 80
-for name, fl in (("full", nb.FLAG_NO_COHERENT_SORT), ("forced", nb.FLAG_DEBUG_COHERENT_SORT)):
+for name, fl in (("full", nb.FLAG_NO_COHERENT_SORT), ("forced", nb.FLAG_ALWAYS_COHERENT_SORT)):
     with nb.Simulation(nb.Params(num_points=n, morton_bits=21, flags=nb.FLAG_TIMING | nb.FLAG_TIMING_STAGES | fl, seed=42,
                                  theta=0.6, dt=1e-6, softening_factor=0.1)) as s:
         ic = nb.sample_ic(nb.IC_SPHERE, n, 42)

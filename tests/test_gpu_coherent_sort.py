@@ -4,7 +4,7 @@ csrc/k_sort.hip, k_coh_*) must give the stable sort of everything -- the permuta
 passes over all elements, which tests/test_gpu_parity.py pins to the oracle's
 (reference: cub::DeviceMergeSort::SortPairs + thrust::sequence, src/cuda/points.cu:73-84).
 
-NBODY_FLAG_DEBUG_COHERENT_SORT takes the path on every sort after the first whatever share of the
+NBODY_FLAG_ALWAYS_COHERENT_SORT takes the path on every sort after the first whatever share of the
 elements moved, NBODY_FLAG_NO_COHERENT_SORT never: sorted codes and permutation of every step
 and the state at the end are compared bit for bit, and the first steps against the oracle."""
 import numpy as np
@@ -71,7 +71,7 @@ def test_nearly_sorted_path_gives_the_permutation_of_the_digit_passes(case):
         kw = dict(theta=0.7, dt=2e-5, softening_factor=1e-3)
     extra = nb.FLAG_FP64 if case == "fp64" else 0
     full = run(ic, n, steps, nb.FLAG_NO_COHERENT_SORT | extra, **kw)
-    forced = run(ic, n, steps, nb.FLAG_DEBUG_COHERENT_SORT | extra, **kw)
+    forced = run(ic, n, steps, nb.FLAG_ALWAYS_COHERENT_SORT | extra, **kw)
     assert full[2]["coherent_sorts"] == 0 and full[2]["full_sorts"] == steps + 1
     assert forced[2]["coherent_sorts"] == steps and forced[2]["full_sorts"] == 1
     moved = forced[2]["last_moved"]
@@ -102,7 +102,7 @@ def test_nearly_sorted_path_with_equal_keys_and_long_runs_against_the_oracle():
     v[np.all(p == np.array([3.125, 0.625, 2.0], np.float32), axis=1)] = 0     # they stay on one point
     m = np.full(n, 1e-9, np.float32)                                          # (no forces to speak of)
     par = nb.Params(num_points=n, morton_bits=21, theta=0.5, dt=2e-5, softening_factor=0.05,
-                    flags=nb.FLAG_DEBUG_COHERENT_SORT)
+                    flags=nb.FLAG_ALWAYS_COHERENT_SORT)
     with nb.Simulation(par) as sim:
         sim.set_state(p[:, 0].copy(), p[:, 1].copy(), p[:, 2].copy(), m, v[:, 0].copy(), v[:, 1].copy(), v[:, 2].copy())
         for step in range(4):
@@ -129,7 +129,7 @@ def test_nearly_sorted_path_with_late_workgroups():
     ic = nb.sample_ic(nb.IC_DISK, n, 2)
     kw = dict(theta=0.9, dt=2e-4, softening_factor=1e-3)
     a = run(ic, n, 3, nb.FLAG_NO_COHERENT_SORT, **kw)
-    b = run(ic, n, 3, nb.FLAG_DEBUG_COHERENT_SORT | nb.FLAG_DEBUG_LATE_TILES, **kw)
+    b = run(ic, n, 3, nb.FLAG_ALWAYS_COHERENT_SORT | nb.FLAG_DEBUG_LATE_TILES, **kw)
     assert b[2]["coherent_sorts"] == 3
     assert b[2]["last_moved"] > 256 * 4096      # more tiles of moved elements than workgroups
     assert_same_run(a, b)
