@@ -6,11 +6,12 @@ import numpy as np
 import oracle_lib as O
 import nbody_amd as nb
 rng = np.random.default_rng(123)
+XF = int(os.environ.get("NBODY_EXTRA_FLAGS", "0"))   # e.g. 2048: every sort by the nearly-sorted path
 t0 = time.time()
 bad = 0
 n = 200_000
 for bits in (21, 10):
-    with nb.Simulation(nb.Params(num_points=n, morton_bits=bits, theta=0.6, softening_factor=0.01)) as sim:
+    with nb.Simulation(nb.Params(num_points=n, morton_bits=bits, theta=0.6, softening_factor=0.01, flags=XF)) as sim:
         for it in range(40):
             k = rng.integers(1, 12)
             c = rng.uniform(0.5, 4.5, (k, 3))
@@ -28,7 +29,7 @@ for bits in (21, 10):
 # long run
 n = 1 << 20
 ic = nb.sample_ic(nb.IC_PLUMMER, n, 7, p0=0.1, p1=1.0)
-with nb.Simulation(nb.Params(num_points=n, morton_bits=21, theta=0.6, dt=2e-4, softening_factor=2e-3)) as sim:
+with nb.Simulation(nb.Params(num_points=n, morton_bits=21, theta=0.6, dt=2e-4, softening_factor=2e-3, flags=XF)) as sim:
     sim.set_state(ic["x"], ic["y"], ic["z"], ic["m"])
     sim.step(1)
     e0 = sum(sim.tree_energy())
@@ -38,4 +39,5 @@ with nb.Simulation(nb.Params(num_points=n, morton_bits=21, theta=0.6, dt=2e-4, s
         st = sim.get_state()
         print("steps", (blk + 1) * 1000, "E", e, "rel change", (e - e0) / abs(e0), "finite", bool(np.isfinite(st["ax"]).all()),
               "n_oct", sim.get_num_octree_nodes(), round(time.time() - t0, 1), "s", flush=True)
+    print("sorts", sim.sort_stats())
 print("SOAK DONE mismatches", bad)
