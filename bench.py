@@ -617,8 +617,10 @@ def main():
                          "moved_elements_last_step": st9["last_moved"]}
         slow = {"workload": "2,097,152-particle Plummer sphere at rest (total mass 1), theta=%.2f, eps=1e-3, dt=1e-6, "
                             "63-bit keys, one update then a wait per step" % THETA, **res,
-                "note": "the timed region of this line queues its steps without waiting, so its sorts cannot "
-                        "know how the previous one went and run the digit passes over all elements"}
+                "note": "the library takes the shorter sort when the previous sort (finished by then) moved at most "
+                        "1 element in 64, or when the last three counts it has seen moved at most 1 in 1024; the "
+                        "sphere of this line's timed region starts from rest and accelerates (none moved in step 1, "
+                        "a quarter of all by step 130), so its sorts are digit passes over all elements"}
     direct = None
     if world == 1 and not args.no_direct_sum and not args.walk_only:
         direct = direct_sum_block(args.no_cpu_baseline)

@@ -85,10 +85,12 @@ enum {
                                           the uniform cube, src/renderer.cpp:314-318) sorts only the
                                           elements whose key left the gap between their neighbours'
                                           previous keys and merges them into the rest, which is in
-                                          order already -- the same permutation as the full sort,
-                                          chosen from the count of such elements a previous step
-                                          reported.  This flag always runs the digit passes over
-                                          all elements.                                        */
+                                          order already -- the same permutation as the full sort.
+                                          The library takes that path when the previous sort has
+                                          finished and moved at most 1 element in 64, or when the
+                                          last three counts it has seen (at most 256 sorts old) moved
+                                          at most 1 in 1024.  This flag always runs the digit passes
+                                          over all elements.                                    */
     NBODY_FLAG_ALWAYS_COHERENT_SORT = 1u << 11, /* take that path on every sort whose predecessor's
                                             keys are there, however many elements moved and whether or
                                             not the previous sort has finished: for a caller that

@@ -138,8 +138,8 @@ int alloc_all(Sim *s)
     if (s->key_bytes == 8) {
         NB_HIP(s, dalloc(&s->coh_ctl, 4));
         NB_HIP(s, hipMemsetAsync(s->coh_ctl, 0, 16, s->stream));
-        NB_HIP(s, hipHostMalloc((void **) &s->coh_host, 2 * sizeof(int32_t)));
-        s->coh_host[0] = -1; s->coh_host[1] = 0;
+        NB_HIP(s, hipHostMalloc((void **) &s->coh_host, 4 * sizeof(int32_t)));
+        s->coh_host[0] = -1; s->coh_host[1] = 0; s->coh_host[2] = 0; s->coh_host[3] = 0;
         NB_HIP(s, hipEventCreateWithFlags(&s->ev_hint, hipEventDisableTiming));
     }
     NB_HIP(s, dalloc(&s->depth_rows, (size_t) 2048 * 32));

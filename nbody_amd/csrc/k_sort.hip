@@ -460,10 +460,11 @@ constexpr int COH_TILE = 256 * COH_ITEMS;        // 2048 elements = 32 ballot wo
 constexpr int COH_WORDS = COH_TILE / 64;
 constexpr int COH_MERGE_EXTRA = 1024;
 constexpr int COH_SORT_GRID = 256;                // workgroups of a digit pass over the moved elements (they loop)
+constexpr int COH_TINY_SHARE = 1024;              // "hardly any": at most n / 1024 moved
+constexpr int COH_TINY_STREAK = 3;                // that many such counts in a row, and ...
+constexpr int COH_TINY_AGE = 256;                 // ... a count up to this many sorts old is still believed
 constexpr int COH_MAX_SHARE = 64;                // this path when at most n / 64 elements moved last time (break-even: 1 in 52 at 2 M keys)            // workgroups of k_coh_merge that place the moved elements
 
-// k_coh_scan: ctl[0] = moved count; host2[0] = moved count, host2[1] = n (pinned host memory, read
-// by the host without synchronisation: a hint, never an input).
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_coh_flags(const KeyT *__restrict__ knew, const KeyT *__restrict__ kold,
                                                    int n, unsigned long long *__restrict__ bits,
@@ -494,9 +495,13 @@ __global__ __launch_bounds__(256) void k_coh_flags(const KeyT *__restrict__ knew
     if (tid == 0) tile_cnt[tile] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
 }
 
-// Exclusive prefix of the tiles' staying counts, the moved count (one workgroup).
+// Exclusive prefix of the tiles' staying counts, the moved count (one workgroup).  ctl[0] = moved
+// count, ctl[2] = how many counts in a row were at most n / COH_TINY_SHARE, ctl[3] = the n they
+// belong to.  host4 (pinned, read by the host without synchronisation: a hint, never an input) =
+// {moved, n, index of the sort call that counted, that streak}.
 __global__ __launch_bounds__(1024) void k_coh_scan(int n, int ntiles, const uint32_t *__restrict__ tile_cnt,
-                                                   uint32_t *__restrict__ tile_sbase, int32_t *ctl, int32_t *host2)
+                                                   uint32_t *__restrict__ tile_sbase, int32_t *ctl, int32_t *host4,
+                                                   int call)
 {
     __shared__ uint32_t s_scan[17];
     const int tid = threadIdx.x;
@@ -512,8 +517,14 @@ __global__ __launch_bounds__(1024) void k_coh_scan(int n, int ntiles, const uint
     if (tid == 0) {
         const int moved = n - (int) carry;
         ctl[0] = moved;
-        __hip_atomic_store(&host2[1], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&host2[0], moved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const bool tiny = (long long) moved * COH_TINY_SHARE <= (long long) n;
+        const int streak = tiny ? (ctl[3] == n ? ctl[2] : 0) + 1 : 0;
+        ctl[2] = streak;
+        ctl[3] = n;
+        __hip_atomic_store(&host4[3], streak, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host4[2], call, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host4[1], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host4[0], moved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -696,16 +707,24 @@ static hipError_t sort_impl(Sim *s)
             if (s->p.flags & NBODY_FLAG_ALWAYS_COHERENT_SORT) {
                 coherent = true;
             } else {
-                // The moved count the PREVIOUS sort reported, if that sort has finished by now (a
-                // caller that queues many steps without waiting is ahead of the device, and a count
-                // from many steps ago says nothing: a system starting from rest has none moved in
-                // its first step and a quarter a hundred steps later).  Decides which way is
-                // faster, never what comes out.
-                const bool fresh = s->hint_call + 1 == s->sort_calls && s->ev_hint &&
-                                   hipEventQuery(s->ev_hint) == hipSuccess;
+                // The moved count of the PREVIOUS sort, if that sort has finished by now (a caller
+                // that queues many steps without waiting is ahead of the device, and a count from
+                // many steps ago says little: a system starting from rest has none moved in its
+                // first step and a quarter a hundred steps later) -- or an older count, up to
+                // COH_TINY_AGE sorts old, when it and the counts before it found hardly anything
+                // moved (a cold or slow system: queued steps keep the short sort).  Decides which
+                // way is faster, never what comes out.
                 const int hint = s->coh_host[0], hint_n = s->coh_host[1];
-                if (fresh && hint_n == n && hint >= 0 && (long long) hint * COH_MAX_SHARE <= (long long) n) coherent = true;
-                else probe = (s->sort_calls & 7u) == 1u;   // look again now and then
+                const uint32_t hint_call = (uint32_t) s->coh_host[2];
+                const int streak = s->coh_host[3];
+                const uint32_t age = s->sort_calls - hint_call;
+                const bool ok = hint_n == n && hint >= 0 && (long long) hint * COH_MAX_SHARE <= (long long) n;
+                const bool fresh = age == 1 && s->hint_call + 1 == s->sort_calls && s->ev_hint &&
+                                   hipEventQuery(s->ev_hint) == hipSuccess;
+                const bool calm = streak >= COH_TINY_STREAK && (long long) hint * COH_TINY_SHARE <= (long long) n &&
+                                  age >= 1 && age <= (uint32_t) COH_TINY_AGE;
+                if (ok && (fresh || calm)) coherent = true;
+                else probe = s->sort_calls <= 4u || (s->sort_calls & 7u) == 1u;   // look now and then
             }
         }
     }
@@ -718,7 +737,7 @@ static hipError_t sort_impl(Sim *s)
         hipLaunchKernelGGL(k_coh_flags<KeyT>, dim3(ctiles), dim3(256), 0, s->stream, (const KeyT *) s->keys[0],
                            (const KeyT *) s->keys[1], n, bits, tile_cnt);
         hipLaunchKernelGGL(k_coh_scan, dim3(1), dim3(1024), 0, s->stream, n, ctiles, (const uint32_t *) tile_cnt,
-                           tile_sbase, s->coh_ctl, s->coh_host);
+                           tile_sbase, s->coh_ctl, s->coh_host, (int) (s->sort_calls - 1));
         if (s->ev_hint && hipEventRecord(s->ev_hint, s->stream) == hipSuccess) s->hint_call = s->sort_calls - 1;
     }
     if (coherent) {

@@ -148,7 +148,7 @@ struct Sim {
     size_t sort_status_bytes = 0;
     int sort_tiles = 0;
     // sort of nearly sorted keys (k_sort.hip, k_coh_*): device control words, the moved count the
-    // last such pass reported (pinned: {moved, n}), the element count of the keys the last sort left
+    // last such pass reported (pinned: {moved, n, sort call, calm streak}), the element count of the keys the last sort left
     // in keys[sorted_buf], how many sorts went which way
     int32_t *coh_ctl = nullptr;
     int32_t *coh_host = nullptr;
