@@ -518,7 +518,7 @@ int nbody_dd_rebalance(nbody_dd_t *h)
     d->stats.n_local = s->spawned ? s->n : 0;
     if (W == 1) return NBODY_OK;
     const int n_local = s->spawned ? s->n : 0;
-    // ---- round 1: 4096 bins of the top 12 key bits ----
+    // ---- first histogram: 4096 bins of the top 12 key bits ----
     std::vector<uint64_t> q(DD_BINS + 1);
     for (int j = 0; j <= DD_BINS; ++j) q[j] = (uint64_t) j << (KB - DD_BIN_BITS);
     std::vector<int32_t> lb;

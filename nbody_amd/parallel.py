@@ -106,7 +106,7 @@ def morton_splitters(lower_bounds, gather_sum, parts, key_bits, slack_share=DD_S
     nbody_dd_rebalance (csrc/dd.hip) with the collectives injected.
       lower_bounds(q)  positions of the uint64 query keys q in this rank's SORTED keys
       gather_sum(a)    element-wise sum over all ranks of the uint64 array a
-    Round 1 histograms the top 12 key bits (4096 bins) and takes, for every cut, the coarsest
+    The first histogram is over the top 12 key bits (4096 bins) and gives, for every cut, the coarsest
     bin edge within the slack of its target; a cut that no edge meets is refined, round after
     round, with a 4096-bin histogram of the next 12 bits of the bin that holds its target.  Returns
     (splitters uint64[parts + 1], total particle count); splitters[parts] = 2^key_bits."""
