@@ -591,20 +591,32 @@ int nbody_dd_rebalance(nbody_dd_t *h)
     if (rc) return rc;
     lb[0] = 0;
     lb[W] = n_local;
-    std::vector<uint32_t> sc(W);
+    // every rank's send counts, and with them the one mass all of its particles have (0: they
+    // differ or are unknown; all ones: it has no particles) -- if every rank names the same mass the
+    // whole set has it, whoever holds which particle afterwards
+    std::vector<uint32_t> sc((size_t) W + 1);
     for (int r = 0; r < W; ++r) sc[r] = (uint32_t) (lb[r + 1] - lb[r]);
-    DD_HIP(d, hipMemcpyAsync(d->hist_dev, sc.data(), W * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
-    DD_COMM(d, d->comm.all_gather(d->comm.ctx, d->hist_dev, d->hist_all, W * sizeof(uint32_t), (void *) s->stream));
-    std::vector<uint32_t> mat((size_t) W * W);
+    const float own_m0 = (s->fp64 || (s->p.flags & NBODY_FLAG_NO_UNIFORM_MASS)) ? 0.f : s->uniform_mass;
+    sc[W] = n_local > 0 ? __builtin_bit_cast(uint32_t, own_m0) : 0xffffffffu;
+    DD_HIP(d, hipMemcpyAsync(d->hist_dev, sc.data(), (W + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+    DD_COMM(d, d->comm.all_gather(d->comm.ctx, d->hist_dev, d->hist_all, (W + 1) * sizeof(uint32_t), (void *) s->stream));
+    std::vector<uint32_t> mat((size_t) W * (W + 1));
     DD_HIP(d, hipMemcpyAsync(mat.data(), d->hist_all, mat.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     DD_HIP(d, hipStreamSynchronize(s->stream));
+    uint32_t common = 0xffffffffu;   // bit pattern of the set's one mass, 0 = there is none
+    for (int r = 0; r < W; ++r) {
+        const uint32_t v = mat[(size_t) r * (W + 1) + W];
+        if (v == 0xffffffffu) continue;
+        common = (common == 0xffffffffu || common == v) ? v : 0u;
+    }
+    const float global_m0 = (common == 0xffffffffu) ? 0.f : __builtin_bit_cast(float, common);
     size_t total_recv = 0;
     const size_t mb = mig_bytes(s);
     std::vector<size_t> sb(W), so(W), rb(W), ro(W);
     for (int r = 0; r < W; ++r) {
         sb[r] = (size_t) sc[r] * mb;
         so[r] = (size_t) lb[r] * mb;
-        const size_t cnt = mat[(size_t) r * W + me];
+        const size_t cnt = mat[(size_t) r * (W + 1) + me];
         rb[r] = cnt * mb;
         ro[r] = total_recv * mb;
         total_recv += cnt;
@@ -647,6 +659,10 @@ int nbody_dd_rebalance(nbody_dd_t *h)
     if (install_particles_dev(s, (int) total_recv) != NBODY_OK)
         return dfail(d, NBODY_ERR_STATE, std::string("rebalance: ") + nbody_last_error(H(s)));
     DD_NB(d, nbody_sync(H(s)));
+    if (global_m0 > 0.f) {   // (install_particles_dev forgot the mass: these came from other ranks)
+        s->uniform_mass = global_m0;
+        s->forest_uniform = true;
+    }
     d->stats.n_local = (int64_t) total_recv;
     return NBODY_OK;
 }

@@ -32,6 +32,7 @@
 // visited in, so list lengths equal those of the reference's breadth-first walk.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "dev_utils.hpp"
@@ -80,18 +81,20 @@ struct alignas(16) WaveLds {
 // distance -- the body itself -- left out; writes tail->pot and nothing else).
 constexpr int TRAV_FORCE = 0, TRAV_WALK_ONLY = 1, TRAV_POTENTIAL = 2;
 
-// UNI (G = 64, forces only): every particle has the same mass m0.  Particles streamed through
+// UNI != 0 (G = 64, forces only): every particle has the same mass m0.  Particles streamed through
 // the scalar path then skip the multiplication by their mass; the masses of the ring's entries
 // (accepted nodes, odd particles at run ends) are divided by m0 on their way in and the caller
 // passes gravity * m0, so that every sum is in units of m0.  With m0 = 1 (or any power of two)
-// the result is the same bits as the general path's.
-template <int G, bool FUSE_VEL, int MODE, bool UNI = false>
+// the result is the same bits as the general path's.  UNI == 2: particle records from index
+// uni_limit on (imported tree copies, where a pruned subtree travels as one record of its own
+// mass) keep their mass: it is divided by m0 like a ring entry's.
+template <int G, bool FUSE_VEL, int MODE, int UNI = 0>
 __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
     int n, int g0, int g1, const Float4 *__restrict__ body_posm, const Float4 *__restrict__ posm,
     const v8f *__restrict__ posm2, const Float4 *__restrict__ nodeA,
     const NodeB *__restrict__ nodeB, float theta, float eps2, float gravity, float domain,
     float dt, float keep, const TravTail *__restrict__ tail, int cur, int accumulate,
-    int stack_limit, const int32_t *__restrict__ roots, int nroots, float inv_m0)
+    int stack_limit, const int32_t *__restrict__ roots, int nroots, float inv_m0, int uni_limit)
 {
     static_assert(!UNI || (G == 64 && MODE == TRAV_FORCE), "uniform-mass path: wave-wide groups, forces");
     __shared__ WaveLds lds[TRAV_WAVES];
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
     };
 
     // Sources of one pair record held in SGPRs (wave-uniform): no LDS, no VGPR staging.
-    auto pair_force_s = [&](const v8f r) {
+    auto pair_force_s = [&](const v8f r, auto own_mass) {   // own_mass: the record's mass counts (not UNI's m0)
         if (MODE == TRAV_WALK_ONLY) { fx2 += v2f{r[0], r[1]}; return; }
         const v2f dx = v2f{r[0], r[1]} - px2, dy = v2f{r[2], r[3]} - py2, dz = v2f{r[4], r[5]} - pz2;
         const v2f s = __builtin_elementwise_fma(
@@ -221,7 +224,8 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
         }
         const v2f s3 = s * s * s;
         v2f inv = {__builtin_amdgcn_rsqf(s3.x), __builtin_amdgcn_rsqf(s3.y)};
-        if (!UNI) inv *= v2f{r[6], r[7]};
+        if constexpr (!UNI) inv *= v2f{r[6], r[7]};
+        else if constexpr (decltype(own_mass)::value) inv *= v2f{r[6], r[7]} * inv_m0;
         fx2 = __builtin_elementwise_fma(dx, inv, fx2);
         fy2 = __builtin_elementwise_fma(dy, inv, fy2);
         fz2 = __builtin_elementwise_fma(dz, inv, fz2);
@@ -327,19 +331,11 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
         // odd particle at either end of a run -> LDS list (two batched gathers per 64 leaves)
         append_particles(is_head && (pb & 1), pb);
         append_particles(is_tail && (pe & 1), pe - 1);
-        // whole pairs of every run -> scalar path
-        unsigned long long hm = __ballot(is_head);
-        PROF_T0();
-        while (hm) {
-            const int h = (int) __builtin_ctzll(hm);
-            hm &= hm - 1;
-            const int t = (hm ? (int) __builtin_ctzll(hm) : cnt) - 1;   // last lane of the run
-            const int rb = __builtin_amdgcn_readlane(pb, h);
-            const int re = __builtin_amdgcn_readlane(pe, t);
-            total += (uint32_t) (re - rb);
+        // the whole pairs of one run [rb, re) through the scalar path
+        auto run_stream = [&](const int rb, const int re, auto own_mass) {
             int q0 = (rb + 1) >> 1;
             const int q1 = re >> 1;                                     // pairs [q0, q1)
-            if (q0 < q1 && (q0 & 1)) pair_force_s(posm2[q0++]);         // align to 64 B
+            if (q0 < q1 && (q0 & 1)) pair_force_s(posm2[q0++], own_mass);         // align to 64 B
             if (q0 + 1 < q1) {   // two pairs (one 64-byte record) per scalar load, one load ahead;
                                  // two register sets used alternately so nothing is copied
                 const v16f *P16 = reinterpret_cast<const v16f *>(posm2);
@@ -354,20 +350,33 @@ __global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
                     const bool hb = d + 1 < d1;
                     __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): ra has arrived
                     if (hb) rb2 = P16[d + 1];
-                    pair_force_s(ra.lo);
-                    pair_force_s(ra.hi);
+                    pair_force_s(ra.lo, own_mass);
+                    pair_force_s(ra.hi, own_mass);
                     if (!hb) break;
                     const bool ha = d + 2 < d1;
                     __builtin_amdgcn_s_waitcnt(0xC07F);   // rb2 has arrived
                     if (ha) ra = P16[d + 2];
-                    pair_force_s(rb2.lo);
-                    pair_force_s(rb2.hi);
+                    pair_force_s(rb2.lo, own_mass);
+                    pair_force_s(rb2.hi, own_mass);
                     if (!ha) break;
                     d += 2;
                 }
                 q0 = d1 << 1;
             }
-            if (q0 < q1) pair_force_s(posm2[q0]);
+            if (q0 < q1) pair_force_s(posm2[q0], own_mass);
+        };
+        // whole pairs of every run -> scalar path
+        unsigned long long hm = __ballot(is_head);
+        PROF_T0();
+        while (hm) {
+            const int h = (int) __builtin_ctzll(hm);
+            hm &= hm - 1;
+            const int t = (hm ? (int) __builtin_ctzll(hm) : cnt) - 1;   // last lane of the run
+            const int rb = __builtin_amdgcn_readlane(pb, h);
+            const int re = __builtin_amdgcn_readlane(pe, t);
+            total += (uint32_t) (re - rb);
+            if (UNI == 2 && rb >= uni_limit) run_stream(rb, re, std::true_type{});   // an imported copy's records
+            else run_stream(rb, re, std::false_type{});
         }
         PROF_ADD(1);
         asm volatile("" ::"v"(touch[0]), "v"(touch[1]), "v"(touch[2]), "v"(touch[3]));
@@ -732,11 +741,15 @@ static hipError_t traverse_impl(Sim *s, Sim *src, bool fuse_vel, int acc_flag, b
     hipLaunchKernelGGL((k_traverse<GG, FV, (WO), UU>), dim3(grid), dim3(64 * TRAV_WAVES), 0, s->stream, \
                        s->n, g0, g1, s->posm, src->posm, (const v8f *) src->posm2, src->nodeA,       \
                        src->nodeB, s->p.theta, eps2, GRAV, s->p.domain_size, s->p.dt, keep,          \
-                       s->trav_tail, c, acc_flag, stack_limit, roots, nroots, IM0)
-#define NB_TRAV(GG, FV, WO) NB_TRAV_U(GG, FV, WO, false, s->p.gravity, 1.0f)
+                       s->trav_tail, c, acc_flag, stack_limit, roots, nroots, IM0, uni_limit)
+#define NB_TRAV(GG, FV, WO) NB_TRAV_U(GG, FV, WO, 0, s->p.gravity, 1.0f)
         // every source particle has mass m0 (the sources are this handle's own particles and
-        // nothing imported): the uniform-mass variant
-        const float m0 = (src == s && !forest && !(s->p.flags & NBODY_FLAG_NO_UNIFORM_MASS)) ? s->uniform_mass : 0.f;
+        // nothing imported, or copies of the same kind): the uniform-mass variant
+        // (with imported copies only when their particles are known to have that mass too)
+        const float m0 = (src == s && (!forest || s->forest_uniform) && !(s->p.flags & NBODY_FLAG_NO_UNIFORM_MASS))
+                             ? s->uniform_mass : 0.f;
+        // (the copies' particle records start behind the handle's own: nbody_import_trees_dev)
+        const int uni_limit = forest ? ((s->cap + 3) & ~3) : 0x7fffffff;
         const bool walk_only = (s->p.flags & NBODY_FLAG_DEBUG_WALK_ONLY) != 0;
         // test aid: a node stack with 32 usable entries makes unexpanded push-backs and
         // depth-first single-node rounds the common case
@@ -745,9 +758,12 @@ static hipError_t traverse_impl(Sim *s, Sim *src, bool fuse_vel, int acc_flag, b
             if (s->group == 64) NB_TRAV(64, false, TRAV_POTENTIAL); else NB_TRAV(32, false, TRAV_POTENTIAL);
         } else if (walk_only) {
             if (s->group == 64) NB_TRAV(64, false, TRAV_WALK_ONLY); else NB_TRAV(32, false, TRAV_WALK_ONLY);
+        } else if (s->group == 64 && m0 > 0.f && forest) {
+            if (fuse_vel) NB_TRAV_U(64, true, TRAV_FORCE, 2, s->p.gravity * m0, 1.0f / m0);
+            else NB_TRAV_U(64, false, TRAV_FORCE, 2, s->p.gravity * m0, 1.0f / m0);
         } else if (s->group == 64 && m0 > 0.f) {
-            if (fuse_vel) NB_TRAV_U(64, true, TRAV_FORCE, true, s->p.gravity * m0, 1.0f / m0);
-            else NB_TRAV_U(64, false, TRAV_FORCE, true, s->p.gravity * m0, 1.0f / m0);
+            if (fuse_vel) NB_TRAV_U(64, true, TRAV_FORCE, 1, s->p.gravity * m0, 1.0f / m0);
+            else NB_TRAV_U(64, false, TRAV_FORCE, 1, s->p.gravity * m0, 1.0f / m0);
         } else if (s->group == 64) {
             if (fuse_vel) NB_TRAV(64, true, TRAV_FORCE); else NB_TRAV(64, false, TRAV_FORCE);
         } else {

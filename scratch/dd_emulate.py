@@ -36,6 +36,8 @@ for r in range(W):
     s = nb.Simulation(params(len(idx)))
     s.set_state(ic["x"][idx], ic["y"][idx], ic["z"][idx], ic["m"][idx])
     s.set_traversal_range(0, 0)
+    if os.environ.get("DD_NO_UNIFORM") is None and float(ic["m"].min()) == float(ic["m"].max()):
+        s.assume_uniform_mass(float(ic["m"][0]))   # what nbody_dd_rebalance establishes by itself
     sims.append(s)
 
 

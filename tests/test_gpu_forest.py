@@ -270,6 +270,52 @@ def test_forest_run_tracks_single_domain_run_and_regrows():
     d.close()
 
 
+@pytest.mark.parametrize("m0,exact", [(2.0 ** -14, True), (1.0 / 20000, False)])
+def test_forest_walk_with_one_mass_everywhere(m0, exact):
+    """When every particle of every domain has the same mass (what nbody_dd_rebalance finds out, or
+    the caller says with nbody_assume_uniform_mass) the walk over own tree and copies leaves the
+    mass out of the particle-particle arithmetic like the single-handle walk: same lists, the
+    same bits for a power-of-two mass, a few roundings otherwise."""
+    n, world, theta, eps = 20000, 3, 0.6, 0.01
+    ic = nb.sample_ic(nb.IC_SPHERE, n, 5)
+    ic["m"] = np.full(n, m0, np.float32)
+    res = []
+    for assume in (False, True):
+        d = ForestDomains(ic, world, 21, theta, eps)
+        if assume:
+            for s in d.sims:
+                s.assume_uniform_mass(m0)
+        d.step()
+        res.append([(s.get_state(), s.get_list_len().copy()) for s in d.sims])
+        d.close()
+    for (sa, la), (sb, lb) in zip(*res):
+        assert np.array_equal(la, lb)
+        assert np.array_equal(sa["id"], sb["id"])
+        scale = np.sqrt(sa["ax"] ** 2 + sa["ay"] ** 2 + sa["az"] ** 2).astype(np.float64)
+        for k in ("ax", "ay", "az"):
+            if exact:
+                assert np.array_equal(sa[k], sb[k]), k
+            else:
+                assert np.max(np.abs(sa[k].astype(np.float64) - sb[k]) / scale) < 1e-5, k
+    # new particles withdraw the assumption
+    with nb.Simulation(_params(n, 21, theta, eps)) as one:
+        one.set_state(ic["x"], ic["y"], ic["z"], ic["m"])
+        one.assume_uniform_mass(m0)
+        m2 = ic["m"].copy(); m2[::2] *= 3
+        one.set_state(ic["x"], ic["y"], ic["z"], m2)
+        one.set_traversal_range(0, 0)
+        one.update()
+        one.import_trees_dev(0, [], [], [])
+        one.traverse_forest()
+        one.finish_step()
+        a = one.get_state()
+    with nb.Simulation(_params(n, 21, theta, eps)) as two:
+        two.set_state(ic["x"], ic["y"], ic["z"], m2)
+        two.update()
+        b = two.get_state()
+    assert np.array_equal(a["ax"], b["ax"]) and np.array_equal(a["az"], b["az"])
+
+
 def test_forest_without_copies_is_the_plain_traversal():
     n = 8192
     ic = nb.sample_ic(nb.IC_SPHERE, n, 6)
