@@ -250,15 +250,6 @@ int nbody_get_device_ptrs_f64(nbody_t *sim, nbody_dev_view_f64 *out);
  * corner, out[3] = side.  {0, 0, 0, domain_size} without NBODY_FLAG_FIT_KEYS. */
 int nbody_get_key_domain(nbody_t *sim, float *out);
 
-/* Tells a float handle that every particle it holds AND every particle of the tree copies it will
- * import (nbody_import_trees_dev) has mass m0, so that the one walk over own tree and copies
- * may leave the mass out of the particle-particle arithmetic as the single-handle walk does
- * (NBODY_FLAG_NO_UNIFORM_MASS; no counterpart in the reference, whose spawners give every body
- * the same mass, include/cuda/initial_conditions.cuh:41,74,140).  m0 = 0 withdraws it.  Any
- * call that brings new particles (set_state, spawn, snapshot, migration) withdraws it too;
- * nbody_dd_rebalance establishes it by itself when all ranks' particles have one mass. */
-int nbody_assume_uniform_mass(nbody_t *sim, float m0);
-
 /* How the handle's sorts have gone so far (no counterpart in the reference, which sorts with one
  * library call, src/cuda/points.cu:73-84): sorts that took the nearly-sorted path (see
  * NBODY_FLAG_NO_COHERENT_SORT), sorts by digit passes over all elements, and the number of elements

@@ -127,7 +127,6 @@ EXPORTS = [
     "nbody_dd_refine_edge", "nbody_get_key_domain",
     "nbody_let_export_tree_dev", "nbody_import_trees_dev", "nbody_traverse_forest",
     "nbody_dd_set_phase_timing", "nbody_dd_get_phases", "nbody_get_sort_stats",
-    "nbody_assume_uniform_mass",
 ]
 
 _lib = None
@@ -231,7 +230,6 @@ def load_library() -> C.CDLL:
                                          C.c_uint64, C.c_uint64, C.c_int32]
     lib.nbody_dd_refine_edge.restype = C.c_int32
     lib.nbody_get_key_domain.argtypes = [C.c_void_p, fp]
-    lib.nbody_assume_uniform_mass.argtypes = [C.c_void_p, C.c_float]
     lib.nbody_get_sort_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_int32)]
     _lib = lib
@@ -458,10 +456,6 @@ class Simulation:
         out = np.empty(4, np.float32)
         self._check(self._lib.nbody_get_key_domain(self._h, _fptr(out)))
         return out
-
-    def assume_uniform_mass(self, m0: float):
-        """Every particle here and in the tree copies this handle imports has mass m0 (0 = forget)."""
-        self._check(self._lib.nbody_assume_uniform_mass(self._h, float(m0)))
 
     def sort_stats(self) -> dict:
         """Sorts that took the nearly-sorted path, sorts by digit passes over everything, and the

@@ -398,7 +398,6 @@ int upload_state_r(Sim *s, St &a, R4 *tw_posm, R *const tw_v[3], R *const tw_a[3
         bool uni = n > 0 && m[0] > R(1e-30) && m[0] < R(1e30);
         for (size_t i = 1; uni && i < n; ++i) uni = m[i] == m[0];
         s->uniform_mass = uni ? (float) m[0] : 0.f;
-        s->forest_uniform = false;
     }
     NB_HIP(s, hipMemcpyAsync(a.x[c], x, b, hipMemcpyHostToDevice, s->stream));
     NB_HIP(s, hipMemcpyAsync(a.y[c], y, b, hipMemcpyHostToDevice, s->stream));
@@ -594,7 +593,6 @@ int install_particles_dev(Sim *s, int n)
     if (n < 1 || n > s->cap) return fail(s, NBODY_ERR_CAPACITY, "install_particles: count outside [1, num_points]");
     s->n = n;
     s->uniform_mass = 0.f;   // particles of other ranks: their masses are not known here
-    s->forest_uniform = false;
     NB_HIP(s, hipMemsetAsync(s->counts, 0, sizeof(Counts), s->stream));
     NB_HIP(s, s->fp64 ? launch64_morton_only(s) : launch_morton_only(s));
     int rc = build_after_encode(s, true);   // permutes x,y,z,m,v,vh,id: the accelerations ride in vh
@@ -1018,15 +1016,6 @@ int nbody_get_key_domain(nbody_t *h, float *out)
     return NBODY_OK;
 }
 
-int nbody_assume_uniform_mass(nbody_t *h, float m0)
-{
-    NB_ENTER(h);
-    if (!(m0 >= 0.0f) || m0 > 1e30f) return fail(s, NBODY_ERR_INVALID, "assume_uniform_mass: m0 >= 0");
-    s->uniform_mass = (m0 > 1e-30f) ? m0 : 0.f;
-    s->forest_uniform = s->uniform_mass > 0.f;
-    return NBODY_OK;
-}
-
 int nbody_get_sort_stats(nbody_t *h, uint64_t *coherent_sorts, uint64_t *full_sorts, int32_t *last_moved)
 {
     NB_ENTER(h);
@@ -1349,7 +1338,6 @@ int nbody_set_sources_dev(nbody_t *h, const float *posm_dev, int32_t count)
     s->n = count;
     s->pending_vel = false;
     s->uniform_mass = 0.f;
-    s->forest_uniform = false;
     if (count == 0) { s->spawned = false; return NBODY_OK; }
     NB_HIP(s, hipMemsetAsync(s->counts, 0, sizeof(Counts), s->stream));
     NB_HIP(s, launch_unpack_sources(s, reinterpret_cast<const Float4 *>(posm_dev), count));

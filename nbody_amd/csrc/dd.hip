@@ -593,7 +593,8 @@ int nbody_dd_rebalance(nbody_dd_t *h)
     lb[W] = n_local;
     // every rank's send counts, and with them the one mass all of its particles have (0: they
     // differ or are unknown; all ones: it has no particles) -- if every rank names the same mass the
-    // whole set has it, whoever holds which particle afterwards
+    // whole set has it, whoever holds which particle afterwards, and the handle goes on leaving
+    // the mass out of its own particles' pair arithmetic (k_traverse, UNI)
     std::vector<uint32_t> sc((size_t) W + 1);
     for (int r = 0; r < W; ++r) sc[r] = (uint32_t) (lb[r + 1] - lb[r]);
     const float own_m0 = (s->fp64 || (s->p.flags & NBODY_FLAG_NO_UNIFORM_MASS)) ? 0.f : s->uniform_mass;
@@ -659,10 +660,9 @@ int nbody_dd_rebalance(nbody_dd_t *h)
     if (install_particles_dev(s, (int) total_recv) != NBODY_OK)
         return dfail(d, NBODY_ERR_STATE, std::string("rebalance: ") + nbody_last_error(H(s)));
     DD_NB(d, nbody_sync(H(s)));
-    if (global_m0 > 0.f) {   // (install_particles_dev forgot the mass: these came from other ranks)
-        s->uniform_mass = global_m0;
-        s->forest_uniform = true;
-    }
+    // (install_particles_dev forgot the mass, these particles came from other ranks: but they all
+    // have the one mass the whole set has)
+    if (global_m0 > 0.f) s->uniform_mass = global_m0;
     d->stats.n_local = (int64_t) total_recv;
     return NBODY_OK;
 }

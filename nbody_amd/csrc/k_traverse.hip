@@ -743,11 +743,9 @@ static hipError_t traverse_impl(Sim *s, Sim *src, bool fuse_vel, int acc_flag, b
                        src->nodeB, s->p.theta, eps2, GRAV, s->p.domain_size, s->p.dt, keep,          \
                        s->trav_tail, c, acc_flag, stack_limit, roots, nroots, IM0, uni_limit)
 #define NB_TRAV(GG, FV, WO) NB_TRAV_U(GG, FV, WO, 0, s->p.gravity, 1.0f)
-        // every source particle has mass m0 (the sources are this handle's own particles and
-        // nothing imported, or copies of the same kind): the uniform-mass variant
-        // (with imported copies only when their particles are known to have that mass too)
-        const float m0 = (src == s && (!forest || s->forest_uniform) && !(s->p.flags & NBODY_FLAG_NO_UNIFORM_MASS))
-                             ? s->uniform_mass : 0.f;
+        // every particle of the handle has mass m0: the uniform-mass variant
+        // (imported copies' records keep their own mass: the forest walk runs variant 2)
+        const float m0 = (src == s && !(s->p.flags & NBODY_FLAG_NO_UNIFORM_MASS)) ? s->uniform_mass : 0.f;
         // (the copies' particle records start behind the handle's own: nbody_import_trees_dev)
         const int uni_limit = forest ? ((s->cap + 3) & ~3) : 0x7fffffff;
         const bool walk_only = (s->p.flags & NBODY_FLAG_DEBUG_WALK_ONLY) != 0;

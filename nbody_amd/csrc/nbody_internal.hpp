@@ -129,10 +129,6 @@ struct Sim {
     // traversal then leaves the mass out of the particle-particle arithmetic (one packed
     // multiply in fourteen instructions per source pair) and scales at the end.  0 = unknown.
     float uniform_mass = 0.f;
-    // the same holds for every particle of the tree copies this handle imports (other domains of
-    // one particle set: established by nbody_dd_rebalance, or asserted by the caller with
-    // nbody_assume_uniform_mass): the one walk over own tree and copies may then use it too
-    bool forest_uniform = false;
 
     // fitted key domain (NBODY_FLAG_FIT_KEYS): lo xyz, side, valid + 6 words of bounding-box
     // scratch, device memory; null = keys span [0, domain_size]^3 like the reference's

@@ -27,6 +27,8 @@ T = int(os.environ.get("DD_T", nb.LET_MAX_RECORDS))
 
 
 def params(m, **kw):
+    if os.environ.get("DD_NO_UNIFORM"):   # the general kernel: every pair multiplied by its mass
+        kw["flags"] = kw.get("flags", 0) | nb.FLAG_NO_UNIFORM_MASS
     return nb.Params(num_points=m, theta=0.6, dt=1e-6, softening_factor=eps, morton_bits=21, domain_size=5.0, **kw)
 
 
@@ -36,8 +38,6 @@ for r in range(W):
     s = nb.Simulation(params(len(idx)))
     s.set_state(ic["x"][idx], ic["y"][idx], ic["z"][idx], ic["m"][idx])
     s.set_traversal_range(0, 0)
-    if os.environ.get("DD_NO_UNIFORM") is None and float(ic["m"].min()) == float(ic["m"].max()):
-        s.assume_uniform_mass(float(ic["m"][0]))   # what nbody_dd_rebalance establishes by itself
     sims.append(s)
 
 

@@ -37,18 +37,21 @@ def parse_copy(raw, nn, npart, f64=False):
 class ForestDomains:
     """`world` domains on this GPU, stepped with the calls nbody_dd_step makes."""
 
-    def __init__(self, ic, world, bits, theta, eps=0.01, dt=1e-3, records=T, cap_bytes=1024, group=64, f64=False):
+    def __init__(self, ic, world, bits, theta, eps=0.01, dt=1e-3, records=T, cap_bytes=1024, group=64, f64=False,
+                 flags=0, masses=None):
         self.parts = key_ranges(ic, world, bits)
         self.nb, self.pb = (48, 32) if f64 else (32, 16)       # bytes per node and particle record
         self.records, self.cap = records, cap_bytes           # a small capacity forces a regrow
         self.sims = []
-        for idx in self.parts:
+        for r, idx in enumerate(self.parts):
             p = _params(len(idx), bits, theta, eps, dt)
             p.traversal_group_size = group
+            p.flags |= flags
             if f64:
                 p.flags |= nb.FLAG_FP64
             s = nb.Simulation(p)
-            s.set_state(ic["x"][idx], ic["y"][idx], ic["z"][idx], ic["m"][idx], ic["vx"][idx],
+            m = ic["m"][idx] if masses is None else np.full(len(idx), masses[r], ic["m"].dtype)   # one mass per domain
+            s.set_state(ic["x"][idx], ic["y"][idx], ic["z"][idx], m, ic["vx"][idx],
                         ic["vy"][idx], ic["vz"][idx])
             s.set_traversal_range(0, 0)                       # update() = build only
             self.sims.append(s)
@@ -270,50 +273,31 @@ def test_forest_run_tracks_single_domain_run_and_regrows():
     d.close()
 
 
-@pytest.mark.parametrize("m0,exact", [(2.0 ** -14, True), (1.0 / 20000, False)])
-def test_forest_walk_with_one_mass_everywhere(m0, exact):
-    """When every particle of every domain has the same mass (what nbody_dd_rebalance finds out, or
-    the caller says with nbody_assume_uniform_mass) the walk over own tree and copies leaves the
-    mass out of the particle-particle arithmetic like the single-handle walk: same lists, the
-    same bits for a power-of-two mass, a few roundings otherwise."""
+@pytest.mark.parametrize("masses,exact", [((2.0 ** -14,) * 3, True), ((1.0 / 20000,) * 3, False),
+                                          ((3e-5, 7e-5, 5e-5), False)])
+def test_forest_walk_of_domains_with_one_mass_each(masses, exact):
+    """A handle whose own particles all have one mass leaves it out of their pair arithmetic, in
+    the walk over own tree and copies too; the copies' records keep their masses (a pruned subtree
+    travels as one record of its own mass, and another domain may have another mass).  Against
+    the general kernel (NBODY_FLAG_NO_UNIFORM_MASS): same lists, the same bits for power-of-two
+    masses, a few roundings otherwise."""
     n, world, theta, eps = 20000, 3, 0.6, 0.01
     ic = nb.sample_ic(nb.IC_SPHERE, n, 5)
-    ic["m"] = np.full(n, m0, np.float32)
     res = []
-    for assume in (False, True):
-        d = ForestDomains(ic, world, 21, theta, eps)
-        if assume:
-            for s in d.sims:
-                s.assume_uniform_mass(m0)
+    for general in (True, False):
+        d = ForestDomains(ic, world, 21, theta, eps, flags=nb.FLAG_NO_UNIFORM_MASS if general else 0, masses=masses)
         d.step()
         res.append([(s.get_state(), s.get_list_len().copy()) for s in d.sims])
         d.close()
     for (sa, la), (sb, lb) in zip(*res):
         assert np.array_equal(la, lb)
         assert np.array_equal(sa["id"], sb["id"])
-        scale = np.sqrt(sa["ax"] ** 2 + sa["ay"] ** 2 + sa["az"] ** 2).astype(np.float64)
+        scale = np.sqrt(sa["ax"].astype(np.float64) ** 2 + sa["ay"] ** 2 + sa["az"] ** 2)
         for k in ("ax", "ay", "az"):
             if exact:
                 assert np.array_equal(sa[k], sb[k]), k
             else:
                 assert np.max(np.abs(sa[k].astype(np.float64) - sb[k]) / scale) < 1e-5, k
-    # new particles withdraw the assumption
-    with nb.Simulation(_params(n, 21, theta, eps)) as one:
-        one.set_state(ic["x"], ic["y"], ic["z"], ic["m"])
-        one.assume_uniform_mass(m0)
-        m2 = ic["m"].copy(); m2[::2] *= 3
-        one.set_state(ic["x"], ic["y"], ic["z"], m2)
-        one.set_traversal_range(0, 0)
-        one.update()
-        one.import_trees_dev(0, [], [], [])
-        one.traverse_forest()
-        one.finish_step()
-        a = one.get_state()
-    with nb.Simulation(_params(n, 21, theta, eps)) as two:
-        two.set_state(ic["x"], ic["y"], ic["z"], m2)
-        two.update()
-        b = two.get_state()
-    assert np.array_equal(a["ax"], b["ax"]) and np.array_equal(a["az"], b["az"])
 
 
 def test_forest_without_copies_is_the_plain_traversal():

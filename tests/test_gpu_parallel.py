@@ -191,6 +191,11 @@ sim = nb.Simulation(nb.Params(num_points=cap, morton_bits=bits, theta=0.6, dt=1e
                               softening_factor=0.01, device_id=0, seed=5, flags=nb.FLAG_TIMING | fit))
 dd = parallel.DomainDecomposition(sim, "cuda:0", via_host=True)
 dd.spawn(nb.IC_SPHERE, n)
+if mode == "two_masses":     # every rank's particles have one mass, but not the same one everywhere
+    st = sim.get_state()
+    sim.set_particles(st["x"], st["y"], st["z"], st["m"] * (2.0 if rank == 0 else 1.0), st["vx"], st["vy"], st["vz"],
+                      st["ax"], st["ay"], st["az"], id=st["id"])
+    dd.rebalance()
 st0 = dd.stats()
 keys0 = sim.get_octree()["codes_sorted"]
 dd.step()
@@ -290,3 +295,34 @@ def test_native_domain_decomposition_processes_share_the_gpu(tmp_path, world, n,
     mean_one, max_one = O.acc_error(s1["ax"], s1["ay"], s1["az"], *ref)
     assert errs["1"][0] < 1.5 * mean_one, (errs, mean_one)
     assert errs["1"][1] < 3 * max_one + 5e-2, (errs, max_one)
+
+
+def test_native_domain_decomposition_with_one_mass_per_rank_but_not_overall(tmp_path):
+    """Rank 0's particles all have mass 2, the others' mass 1: each handle alone would leave the
+    mass out of its pair arithmetic, the walk over own tree and imported copies must not (the
+    re-balancing compares the ranks' masses).  Forces against a float64 direct sum with the real
+    masses, after the first step and after a second re-balance has mixed the two kinds."""
+    world, n, bits = 3, 9000, 21
+    script = tmp_path / "worker.py"
+    script.write_text(_DD_WORKER)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(n), str(tmp_path), str(bits), "two_masses"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for p in procs:
+        out, _ = p.communicate(timeout=170)
+        assert p.returncode == 0, out
+    res = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    for tag in ("1", ""):
+        full = {k: np.full(n, np.nan, np.float32) for k in ("x", "y", "z", "m", "ax", "ay", "az")}
+        for d in res:
+            for k in full:
+                full[k][d["gid" + tag]] = d[k + tag]
+        assert not np.isnan(full["x"]).any()
+        heavy = int((full["m"] == 2.0).sum())
+        assert 0.3 * n < heavy < 0.37 * n and int((full["m"] == 1.0).sum()) == n - heavy
+        ref = O.direct_f64(full["x"], full["y"], full["z"], full["m"], 0.01, 1.0)
+        mean, mx = O.acc_error(full["ax"], full["ay"], full["az"], *ref)
+        assert mean < 1e-2 and mx < 0.3, (tag, mean, mx)
