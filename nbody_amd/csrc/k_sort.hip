@@ -17,10 +17,10 @@
 //                 once per pass: 2*(sizeof(KeyT)+4) bytes per element per pass.
 //   63-bit keys: the passes sort on the upper 40 bits only (5 passes instead of 8); elements
 //                 whose upper 40 bits agree -- a cell of domain / 2^13 -- are then ordered on
-//                 the remaining 24 bits where they lie: k_tiefix (one thread per run of equal
-//                 upper bits, ranked in registers; runs are 2-3 long in practice) and, for runs
-//                 longer than TIE_SHORT, k_tiefix_long (one wave per run, stable 8-bit LSD
-//                 passes within the run).  The result is the stable sort on the whole key.
+//                 the remaining 24 bits where they lie, by k_tiefix: one thread per run of equal
+//                 upper bits, ranked in registers (runs are 2-3 long in practice); a run longer
+//                 than TIE_SHORT is taken by the whole wave of its head (stable 8-bit LSD passes
+//                 within the run).  The result is the stable sort on the whole key.
 #include "dev_utils.hpp"
 #include "nbody_internal.hpp"
 
@@ -111,8 +111,7 @@ constexpr int TIE_SHORT = 16;   // longest run one thread orders (in registers);
 constexpr int TIE_REG = TIE_SHORT;
 
 template <typename KeyT>
-__device__ __forceinline__ void tiefix_at(KeyT *keys, uint32_t *vals, int n, int low_bits,
-                                          uint32_t *__restrict__ long_runs, uint32_t *long_count, int i)
+__device__ __forceinline__ bool tiefix_at(KeyT *keys, uint32_t *vals, int n, int low_bits, int i)
 {
     const bool in = i < n;
     const int ci = in ? i : n - 1;
@@ -122,7 +121,7 @@ __device__ __forceinline__ void tiefix_at(KeyT *keys, uint32_t *vals, int n, int
     const KeyT kn = keys[min(ci + 1, n - 1)], kp = keys[max(ci - 1, 0)];
     const KeyT h = k0 >> low_bits;
     const bool head = in && i + 1 < n && (kn >> low_bits) == h && !(i > 0 && (kp >> low_bits) == h);
-    if (!head) return;
+    if (!head) return false;
     // only the heads go on (a few lanes of a wave).  Runs of two or three first: they are nearly
     // all there is.
     const KeyT k2 = keys[min(i + 2, n - 1)], k3 = keys[min(i + 3, n - 1)];
@@ -133,7 +132,7 @@ __device__ __forceinline__ void tiefix_at(KeyT *keys, uint32_t *vals, int n, int
             keys[i] = kn; keys[i + 1] = k0;
             vals[i] = v1; vals[i + 1] = v0;
         }
-        return;
+        return false;
     }
     if (!t3) {   // three elements: stable ranks
         const uint32_t v0 = vals[i], v1 = vals[i + 1], v2 = vals[i + 2];
@@ -143,7 +142,7 @@ __device__ __forceinline__ void tiefix_at(KeyT *keys, uint32_t *vals, int n, int
             keys[i + r1] = kn; vals[i + r1] = v1;
             keys[i + r2] = k2; vals[i + r2] = v2;
         }
-        return;
+        return false;
     }
     // longer: the TIE_REG - 1 keys after the head's own, fetched together
     KeyT k[TIE_REG];
@@ -155,10 +154,7 @@ __device__ __forceinline__ void tiefix_at(KeyT *keys, uint32_t *vals, int n, int
 #pragma unroll
     for (int a = 2; a < TIE_REG; ++a)
         if (L == a && i + a < n && (k[a] >> low_bits) == h) L = a + 1;
-    if (L == TIE_REG && i + L < n && (keys[i + L] >> low_bits) == h) {   // longer than a thread takes
-        long_runs[atomicAdd(long_count, 1u)] = (uint32_t) i;
-        return;
-    }
+    if (L == TIE_REG && i + L < n && (keys[i + L] >> low_bits) == h) return true;   // longer than a thread takes
     // rank every element of the run among the others (equal keys by position) and move those
     // that are out of place; all reads come before the writes
     uint32_t v[TIE_REG];
@@ -174,94 +170,101 @@ __device__ __forceinline__ void tiefix_at(KeyT *keys, uint32_t *vals, int n, int
             if (r != a) { keys[i + r] = k[a]; vals[i + r] = v[a]; }
         }
     }
+    return false;
 }
 
+// One wave orders one long run: low_bits / 8 stable 8-bit LSD passes over the run, between the
+// run's place in the sorted buffers (k0, v0) and the same place in the other buffer pair (k1, v1),
+// whose contents are dead after the digit passes.  64 elements at a time, in order: lanes with
+// the same digit rank themselves by ballot matching, the digit's running offset lives in LDS
+// (base: 256 words of the wave's own).  All 64 lanes call it with the same arguments.
+template <typename KeyT>
+__device__ __forceinline__ void tiefix_long_run(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1, int n,
+                                                int low_bits, int start, uint32_t *base)
+{
+    const int lane = threadIdx.x & 63;
+    const KeyT h = k0[start] >> low_bits;
+    int L = 0;   // length of the run: first position whose upper bits differ
+    while (true) {
+        const int j = start + L + lane;
+        const unsigned long long same = __ballot(j < n && (k0[j] >> low_bits) == h);
+        if (same != ~0ull) { L += __ffsll((long long) ~same) - 1; break; }
+        L += 64;
+    }
+    KeyT *ks = k0 + start, *kd = k1 + start;
+    uint32_t *vs = v0 + start, *vd = v1 + start;
+    const int passes = low_bits / 8;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = 8 * p;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) base[lane * 4 + q] = 0;
+        __builtin_amdgcn_wave_barrier();
+        for (int j = lane; j < L; j += 64) atomicAdd(&base[(uint32_t) (ks[j] >> shift) & 255u], 1u);
+        __builtin_amdgcn_wave_barrier();
+        // exclusive scan of the 256 counts: four bins per lane
+        uint32_t c[4], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { c[q] = base[lane * 4 + q]; sum += c[q]; }
+        uint32_t off = wave_incl_scan_u32(sum) - sum;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { base[lane * 4 + q] = off; off += c[q]; }
+        __builtin_amdgcn_wave_barrier();
+        for (int j0 = 0; j0 < L; j0 += 64) {
+            const int j = j0 + lane;
+            const bool valid = j < L;
+            const KeyT kk = valid ? ks[j] : (KeyT) 0;
+            const uint32_t vv = valid ? vs[j] : 0u;
+            const uint32_t d = (uint32_t) (kk >> shift) & 255u;
+            unsigned long long m = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const unsigned long long bb = __ballot(bit);
+                m &= bit ? bb : ~bb;
+            }
+            const uint32_t rnk = (uint32_t) mbcnt(m);
+            const uint32_t at = base[d] + rnk;
+            __builtin_amdgcn_wave_barrier();
+            if (valid) {
+                kd[at] = kk;
+                vd[at] = vv;
+                if (rnk == 0) base[d] = at + (uint32_t) __popcll(m);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // what this pass stored is read by other lanes of the wave in the next one
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        KeyT *tk = ks; ks = kd; kd = tk;
+        uint32_t *tv = vs; vs = vd; vd = tv;
+    }
+    if (passes & 1) {   // the run ended up in the other buffer pair
+        for (int j = lane; j < L; j += 64) { kd[j] = ks[j]; vd[j] = vs[j]; }
+    }
+}
+
+// Every thread looks at one element; a run's head orders the run if it is short; the long ones
+// (dense cores, coincident particles: rare) are then taken one after the other by the whole wave
+// of the head that found them.  While a wave reorders its long run the other threads that look at
+// elements of that run see some key of the run -- always one with the run's upper bits, which is
+// all they compare -- so nothing else depends on the order inside it.
 // (grid-stride: the launch may have fewer workgroups than n / 256, e.g. when n is a device-side count)
 template <typename KeyT>
-__global__ __launch_bounds__(256) void k_tiefix(KeyT *keys, uint32_t *vals, int n_host, int low_bits,
-                                                uint32_t *__restrict__ long_runs,
-                                                uint32_t *long_count, const int32_t *n_dev)
-{
-    const int n = n_dev ? *n_dev : n_host;
-    for (int b = (int) blockIdx.x; b * 256 < n; b += (int) gridDim.x)
-        tiefix_at<KeyT>(keys, vals, n, low_bits, long_runs, long_count, b * 256 + (int) threadIdx.x);
-}
-
-// One wave per long run: low_bits / 8 stable 8-bit LSD passes over the run, between the run's
-// place in the sorted buffers (k0, v0) and the same place in the other buffer pair (k1, v1),
-// whose contents are dead after the digit passes.  64 elements at a time, in order: lanes with
-// the same digit rank themselves by ballot matching, the digit's running offset lives in LDS.
-template <typename KeyT>
-__global__ __launch_bounds__(256) void k_tiefix_long(KeyT *k0, uint32_t *v0, KeyT *k1, uint32_t *v1,
-                                                     int n_host, int low_bits,
-                                                     const uint32_t *__restrict__ long_runs,
-                                                     const uint32_t *long_count, const int32_t *n_dev)
+__global__ __launch_bounds__(256) void k_tiefix(KeyT *keys, uint32_t *vals, KeyT *keys_other, uint32_t *vals_other,
+                                                int n_host, int low_bits, const int32_t *n_dev)
 {
     __shared__ uint32_t s_base[4][256];
     const int n = n_dev ? *n_dev : n_host;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t *base = s_base[w];
-    const int nruns = (int) __hip_atomic_load(long_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int r = blockIdx.x * 4 + w; r < nruns; r += gridDim.x * 4) {
-        const int start = (int) long_runs[r];
-        const KeyT h = k0[start] >> low_bits;
-        int L = 0;   // length of the run: first position whose upper bits differ
-        while (true) {
-            const int j = start + L + lane;
-            const unsigned long long same = __ballot(j < n && (k0[j] >> low_bits) == h);
-            if (same != ~0ull) { L += __ffsll((long long) ~same) - 1; break; }
-            L += 64;
-        }
-        KeyT *ks = k0 + start, *kd = k1 + start;
-        uint32_t *vs = v0 + start, *vd = v1 + start;
-        const int passes = low_bits / 8;
-        for (int p = 0; p < passes; ++p) {
-            const int shift = 8 * p;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) base[lane * 4 + q] = 0;
-            __builtin_amdgcn_wave_barrier();
-            for (int j = lane; j < L; j += 64) atomicAdd(&base[(uint32_t) (ks[j] >> shift) & 255u], 1u);
-            __builtin_amdgcn_wave_barrier();
-            // exclusive scan of the 256 counts: four bins per lane
-            uint32_t c[4], sum = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { c[q] = base[lane * 4 + q]; sum += c[q]; }
-            uint32_t off = wave_incl_scan_u32(sum) - sum;
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { base[lane * 4 + q] = off; off += c[q]; }
-            __builtin_amdgcn_wave_barrier();
-            for (int j0 = 0; j0 < L; j0 += 64) {
-                const int j = j0 + lane;
-                const bool valid = j < L;
-                const KeyT kk = valid ? ks[j] : (KeyT) 0;
-                const uint32_t vv = valid ? vs[j] : 0u;
-                const uint32_t d = (uint32_t) (kk >> shift) & 255u;
-                unsigned long long m = __ballot(valid);
-#pragma unroll
-                for (int b = 0; b < 8; ++b) {
-                    const bool bit = (d >> b) & 1u;
-                    const unsigned long long bb = __ballot(bit);
-                    m &= bit ? bb : ~bb;
-                }
-                const uint32_t rnk = (uint32_t) mbcnt(m);
-                const uint32_t at = base[d] + rnk;
-                __builtin_amdgcn_wave_barrier();
-                if (valid) {
-                    kd[at] = kk;
-                    vd[at] = vv;
-                    if (rnk == 0) base[d] = at + (uint32_t) __popcll(m);
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-            // what this pass stored is read by other lanes of the wave in the next one
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            KeyT *tk = ks; ks = kd; kd = tk;
-            uint32_t *tv = vs; vs = vd; vd = tv;
-        }
-        if (passes & 1) {   // the run ended up in the other buffer pair
-            for (int j = lane; j < L; j += 64) { kd[j] = ks[j]; vd[j] = vs[j]; }
+    const int w = threadIdx.x >> 6;
+    for (int b = (int) blockIdx.x; b * 256 < n; b += (int) gridDim.x) {
+        const int i = b * 256 + (int) threadIdx.x;
+        const bool is_long = tiefix_at<KeyT>(keys, vals, n, low_bits, i);
+        unsigned long long lm = __ballot(is_long);
+        while (lm) {
+            const int f = (int) __builtin_ctzll(lm);
+            lm &= lm - 1;
+            tiefix_long_run<KeyT>(keys, vals, keys_other, vals_other, n, low_bits, b * 256 + (w << 6) + f, s_base[w]);
         }
     }
 }
@@ -758,13 +761,8 @@ static hipError_t sort_impl(Sim *s)
                                st + (size_t) tiles * 256, tickets + p, help, late, &s->counts->err);
             in ^= 1;
         }
-        uint32_t *long_runs = (uint32_t *) s->rt_lb;
-        uint32_t *long_count = tickets + 8;
-        hipLaunchKernelGGL(k_tiefix<KeyT>, dim3(std::min((n + 255) / 256, 1024)), dim3(256), 0, s->stream, kb[in], vb[in], 0,
-                           8 * P0, long_runs, long_count, n_moved);
-        hipLaunchKernelGGL(k_tiefix_long<KeyT>, dim3(std::min((n / TIE_SHORT + 3) / 4 + 1, 256)), dim3(256), 0,
-                           s->stream, kb[in], vb[in], kb[in ^ 1], vb[in ^ 1], 0, 8 * P0,
-                           (const uint32_t *) long_runs, (const uint32_t *) long_count, n_moved);
+        hipLaunchKernelGGL(k_tiefix<KeyT>, dim3(std::min((n + 255) / 256, 1024)), dim3(256), 0, s->stream, kb[in], vb[in],
+                           kb[in ^ 1], vb[in ^ 1], 0, 8 * P0, n_moved);
         // merged result -> the first pair, which then becomes keys[1] / vals[1]; the old sorted
         // keys' buffer serves as the unique-key buffer from here on
         hipLaunchKernelGGL(k_coh_merge<KeyT>, dim3(ctiles + COH_MERGE_EXTRA), dim3(256), 0, s->stream,
@@ -808,16 +806,10 @@ static hipError_t sort_impl(Sim *s)
     s->old_keys_n = n;
     ++s->full_sorts;
     if (P0 > 0) {
-        // runs of equal upper bits: heads of the long ones are listed in the (not yet used)
-        // unique-key buffer, counted in a spare ticket word of the block zeroed above
-        uint32_t *long_runs = (uint32_t *) s->unique;
-        uint32_t *long_count = tickets + 8;
+        // runs of equal upper bits, ordered where they lie (the other buffer pair is scratch)
         KeyT *k0 = (KeyT *) s->keys[in], *k1 = (KeyT *) s->keys[in ^ 1];
-        hipLaunchKernelGGL(k_tiefix<KeyT>, dim3((n + 255) / 256), dim3(256), 0, s->stream, k0,
-                           s->vals[in], n, 8 * P0, long_runs, long_count, (const int32_t *) nullptr);
-        hipLaunchKernelGGL(k_tiefix_long<KeyT>, dim3(std::min((n / TIE_SHORT + 3) / 4 + 1, 256)), dim3(256), 0,
-                           s->stream, k0, s->vals[in], k1, s->vals[in ^ 1], n, 8 * P0,
-                           (const uint32_t *) long_runs, (const uint32_t *) long_count, (const int32_t *) nullptr);
+        hipLaunchKernelGGL(k_tiefix<KeyT>, dim3((n + 255) / 256), dim3(256), 0, s->stream, k0, s->vals[in], k1,
+                           s->vals[in ^ 1], n, 8 * P0, (const int32_t *) nullptr);
     }
     return hipGetLastError();
 }
