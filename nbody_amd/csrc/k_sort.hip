@@ -726,8 +726,16 @@ static hipError_t sort_impl(Sim *s)
                                    hipEventQuery(s->ev_hint) == hipSuccess;
                 const bool calm = streak >= COH_TINY_STREAK && (long long) hint * COH_TINY_SHARE <= (long long) n &&
                                   age >= 1 && age <= (uint32_t) COH_TINY_AGE;
-                if (ok && (fresh || calm)) coherent = true;
-                else probe = s->sort_calls <= 4u || (s->sort_calls & 7u) == 1u;   // look now and then
+                if (ok && (fresh || calm)) {
+                    coherent = true;
+                    s->probe_interval = 8;
+                } else if (s->sort_calls <= 4u || s->sort_calls >= s->next_probe) {
+                    // look now and then: the first four sorts, then at growing intervals (a system
+                    // that never qualifies pays one counting pass in 64 sorts)
+                    probe = true;
+                    if (s->sort_calls > 4u) s->probe_interval = std::min(2 * s->probe_interval, 64u);
+                    s->next_probe = s->sort_calls + s->probe_interval;
+                }
             }
         }
     }

@@ -154,6 +154,7 @@ struct Sim {
     int32_t *coh_host = nullptr;
     int old_keys_n = -1;
     uint32_t sort_calls = 0;
+    uint32_t probe_interval = 8, next_probe = 0;   // when the moved elements are counted without the path being taken
     hipEvent_t ev_hint = nullptr;   // after the kernel that reports the moved count
     uint32_t hint_call = ~0u - 1;   // the sort call (0-based) that recorded it
     uint64_t coh_sorts = 0, full_sorts = 0;
