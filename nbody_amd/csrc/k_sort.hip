@@ -461,12 +461,12 @@ void launch_rank_pass(const uint32_t *keys, uint32_t *keys_out, uint32_t *vals_o
 constexpr int COH_ITEMS = 8;
 constexpr int COH_TILE = 256 * COH_ITEMS;        // 2048 elements = 32 ballot words per tile
 constexpr int COH_WORDS = COH_TILE / 64;
-constexpr int COH_MERGE_EXTRA = 1024;
+constexpr int COH_MERGE_EXTRA = 1024;             // workgroups of k_coh_merge that place the moved elements
 constexpr int COH_SORT_GRID = 256;                // workgroups of a digit pass over the moved elements (they loop)
+constexpr int COH_MAX_SHARE = 64;                 // the path pays up to about n / 52 moved (2 M keys): taken up to n / 64
 constexpr int COH_TINY_SHARE = 1024;              // "hardly any": at most n / 1024 moved
 constexpr int COH_TINY_STREAK = 3;                // that many such counts in a row, and ...
 constexpr int COH_TINY_AGE = 256;                 // ... a count up to this many sorts old is still believed
-constexpr int COH_MAX_SHARE = 64;                // this path when at most n / 64 elements moved last time (break-even: 1 in 52 at 2 M keys)            // workgroups of k_coh_merge that place the moved elements
 
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_coh_flags(const KeyT *__restrict__ knew, const KeyT *__restrict__ kold,
