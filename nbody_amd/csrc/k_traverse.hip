@@ -89,7 +89,7 @@ constexpr int TRAV_FORCE = 0, TRAV_WALK_ONLY = 1, TRAV_POTENTIAL = 2;
 // uni_limit on (imported tree copies, where a pruned subtree travels as one record of its own
 // mass) keep their mass: it is divided by m0 like a ring entry's.
 template <int G, bool FUSE_VEL, int MODE, int UNI = 0>
-__global__ __launch_bounds__(64 * TRAV_WAVES, 5) void k_traverse(
+__global__ __launch_bounds__(64 * TRAV_WAVES, TRAV_OCC) void k_traverse(
     int n, int g0, int g1, const Float4 *__restrict__ body_posm, const Float4 *__restrict__ posm,
     const v8f *__restrict__ posm2, const Float4 *__restrict__ nodeA,
     const NodeB *__restrict__ nodeB, float theta, float eps2, float gravity, float domain,

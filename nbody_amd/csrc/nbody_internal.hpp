@@ -43,8 +43,18 @@ constexpr int LET_MASK_DOMAINS = 32;                // remote domains per export
 #define NB_TRAV_WAVES 1
 #endif
 constexpr int TRAV_WAVES = NB_TRAV_WAVES;           // groups (waves) per traversal workgroup
-constexpr int TRAV_STACK = 512;                     // LDS inner-node stack entries per wave
-constexpr int TRAV_LEAF_STACK = 544;                // LDS leaf stack entries per wave
+#ifndef NB_TRAV_STACK
+#define NB_TRAV_STACK 512
+#endif
+#ifndef NB_TRAV_LEAF_STACK
+#define NB_TRAV_LEAF_STACK 544
+#endif
+#ifndef NB_TRAV_OCC
+#define NB_TRAV_OCC 5
+#endif
+constexpr int TRAV_STACK = NB_TRAV_STACK;           // LDS inner-node stack entries per wave
+constexpr int TRAV_LEAF_STACK = NB_TRAV_LEAF_STACK; // LDS leaf stack entries per wave
+constexpr int TRAV_OCC = NB_TRAV_OCC;               // waves per SIMD the traversal is built for (LDS and registers)
 constexpr int TRAV_PEND = 96;                       // LDS queue of candidates awaiting the exact test
 constexpr int MAX_DEPTH_BINS = 256;                 // depth key space of the node ranking pass
 constexpr int TIMING_RING = 64;
